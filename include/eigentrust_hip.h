@@ -1,0 +1,217 @@
+/*
+ * eigentrust_hip.h -- C ABI of the MI355X-native EigenTrust convergence engine.
+ *
+ * The reference (kumavis/protocol, Rust) has no FFI for this path: it is the generic struct
+ * `EigenTrustSet` in eigentrust-zk/src/circuits/dynamic_sets/native.rs with the methods
+ * new / add_member / remove_member / update_op / converge / converge_rational, called from
+ * eigentrust/src/lib.rs:422-440.  eigentrust-zk forbids unsafe code (src/lib.rs:9), so a thin
+ * `-sys` crate binding the functions below is where the reference would link this library.
+ *
+ * Conventions
+ *   - et_fr is the canonical 32-byte little-endian integer < r, i.e. `Fr::to_repr()`
+ *     (eigentrust-zk/src/utils.rs:327-329).  Montgomery form never crosses this boundary.
+ *   - Every function returns 0 (ET_OK) or a negative ET_E_* code; nothing aborts or throws.
+ *     The reference panics instead (assert!/unwrap); each code names the panic it replaces.
+ *   - The caller owns every host buffer passed in or out; the library owns the device memory
+ *     behind et_graph / et_set and keeps no host pointer after a call returns.
+ *   - Calls are synchronous unless the name ends in _async; an et_set / et_graph must not be used
+ *     from two threads at once (the reference's `&mut self`).
+ *   - The hot path runs on the GPU only.  Without a usable HIP device the compute entry points
+ *     return ET_E_NO_DEVICE / ET_E_HIP; there is no CPU fallback.
+ */
+#ifndef EIGENTRUST_HIP_H
+#define EIGENTRUST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint8_t b[32]; } et_fr;
+
+enum {
+    ET_OK = 0,
+    ET_E_DUP_MEMBER = -1,         /* native.rs:178  assert!(pos.is_none())                  */
+    ET_E_SET_FULL = -2,           /* native.rs:181  first_available.unwrap()                */
+    ET_E_NOT_MEMBER = -3,         /* native.rs:192, opinion/native.rs:67                    */
+    ET_E_INSUFFICIENT_PEERS = -4, /* native.rs:289  "Insufficient peers for calculation!"   */
+    ET_E_SUM_MISMATCH = -5,       /* native.rs:334  assert!(sum_initial == sum_final)       */
+    ET_E_NONCANONICAL_FR = -6,    /* a 32-byte value >= r                                   */
+    ET_E_INVALID_ARG = -7,
+    ET_E_HIP = -8,                /* a HIP runtime call failed; see et_last_error_message   */
+    ET_E_NO_DEVICE = -9,
+    ET_E_BUFFER_TOO_SMALL = -10,
+    ET_E_OUT_OF_RANGE = -11,      /* slot / peer index >= number of slots                   */
+    ET_E_UNSUPPORTED = -12
+};
+
+const char *et_strerror(int code);
+/* Detail of the last failure on the calling thread (e.g. the HIP error string). */
+const char *et_last_error_message(void);
+/* ABI version: major << 16 | minor. */
+uint32_t et_abi_version(void);
+/* Number of HIP devices visible, or a negative code. */
+int et_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Set API: mirrors EigenTrustSet (native.rs:109-131) with run-time sizes.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct et_set et_set;
+
+/* EigenTrustSet::new (native.rs:165-172).  num_neighbours / num_iterations / initial_score are
+ * the reference's const generics NUM_NEIGHBOURS, NUM_ITERATIONS, INITIAL_SCORE (u128, given as
+ * two 64-bit halves); production values 4 / 20 / 1000 (circuits/mod.rs:39-43). */
+int et_set_new(uint32_t num_neighbours, uint32_t num_iterations, uint64_t initial_score_lo,
+               uint64_t initial_score_hi, const et_fr *domain, et_set **out);
+void et_set_free(et_set *set);
+
+/* add_member (native.rs:175-186): first empty slot, score = INITIAL_SCORE.
+ * ET_E_DUP_MEMBER / ET_E_SET_FULL; the zero address is ET_E_INVALID_ARG (it marks empty slots). */
+int et_set_add_member(et_set *set, const et_fr *addr);
+/* remove_member (native.rs:189-198): slot -> (0, 0), the member's own opinion row is dropped;
+ * other members' opinions about it stay stored and are nullified at filter time. */
+int et_set_remove_member(et_set *set, const et_fr *addr);
+
+/* update_op (native.rs:201-231) with the part of Opinion::validate (opinion/native.rs:63-109)
+ * that is not signature cryptography: `scores` is the vector validate returns, one field element
+ * per slot (zero where the attestation was absent or its signature invalid).  Scores about
+ * empty slots are stored as zero (opinion/native.rs:92-98).  Replaces any earlier row of `from`.
+ * ET_E_NOT_MEMBER when `from` is not in the set (opinion/native.rs:66-67). */
+int et_set_update_op(et_set *set, const et_fr *from, const et_fr *scores /* num_neighbours */);
+/* The same with only the non-zero entries listed (slots must be < num_neighbours). */
+int et_set_update_op_sparse(et_set *set, const et_fr *from, uint32_t count,
+                            const uint32_t *about_slot, const et_fr *values);
+/* Bulk form for large sets: sender given by slot index, values as small integers (the production
+ * opinion is a u8, eigentrust/src/attestation.rs:304). */
+int et_set_update_op_u32(et_set *set, uint32_t from_slot, uint32_t count,
+                         const uint32_t *about_slot, const uint32_t *values);
+
+/* Slot layout: addresses (zero = empty) and current initial scores, num_neighbours each. */
+int et_set_members(const et_set *set, et_fr *addrs, et_fr *scores);
+
+/* converge (native.rs:286-337) on the GPU: filter, normalise, num_iterations field-exact
+ * iterations, conservation check.  out: num_neighbours scores in slot order, empty slots 0.
+ * ET_E_INSUFFICIENT_PEERS, ET_E_SUM_MISMATCH. */
+int et_set_converge(et_set *set, et_fr *out);
+/* The f64 variant of the same iteration, new = (1-alpha)*(C^T s + dangling term) + alpha*p.
+ * alpha = 0 and pretrust = NULL reproduce converge's update; pretrust (num_neighbours doubles, slot
+ * order) defaults to the initial scores.  residual_l1 (optional) = sum |s_k - s_{k-1}| of the last
+ * iteration.  Scores are on the reference's scale (sum = INITIAL_SCORE * members). */
+int et_set_converge_f64(et_set *set, double alpha, const double *pretrust, double *out,
+                        double *residual_l1);
+/* converge_rational (native.rs:340-392): exact fractions, computed on the host with the library's
+ * own big integers (arbitrary precision has no GPU formulation; usable for small sets only, as in
+ * the reference).  Slot i's reduced numerator / denominator are written as little-endian
+ * magnitudes, zero padded, at num_le + i*stride and den_le + i*stride.  If a value needs more
+ * than `stride` bytes nothing is written, *needed (optional) receives the stride required and
+ * ET_E_BUFFER_TOO_SMALL is returned. */
+int et_set_converge_rational(const et_set *set, uint8_t *num_le, uint8_t *den_le, size_t stride,
+                             size_t *needed);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph engine: what et_set_converge runs on, exposed for large graphs, sharded runs and benches.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct et_graph et_graph;
+
+enum { ET_VARIANT_FR = 1, ET_VARIANT_F64 = 2 };
+
+typedef struct {
+    uint32_t n_seg;         /* GPUs sharing the rows of this graph (1 = whole graph here)        */
+    uint32_t seg;           /* which share this et_graph holds                                   */
+    uint32_t long_row;      /* 0 = default; in-degree above which a row gets a whole wavefront   */
+    uint32_t target_blocks; /* 0 = default; workgroups per iteration launch                      */
+    uint32_t variants;      /* ET_VARIANT_* bit mask; 0 = both                                   */
+    int32_t device;         /* HIP device ordinal; -1 = current device                           */
+} et_build_opts;
+
+typedef struct {
+    uint32_t n;             /* slots                                                             */
+    uint32_t n_valid;       /* members                                                           */
+    uint32_t n_dangling;    /* members whose filtered opinion row is empty                       */
+    uint32_t n_seg, seg;
+    uint64_t nnz;           /* surviving attestations of non-dangling members (all shares)       */
+    uint64_t nnz_local;     /* ... whose rated peer belongs to this share                        */
+    uint64_t padded_local;  /* edge-stream entries incl. padding in this share                   */
+    uint32_t n_slices, n_blocks;
+    uint32_t rows_cap, nd_cap; /* position-space geometry: segment = rows_cap + nd_cap entries   */
+    uint64_t vec_len;       /* entries of one trust vector in position order (all segments)      */
+    uint64_t device_bytes;  /* device memory held by this graph                                  */
+} et_graph_info;
+
+/* Filter + normalise + lay out an attestation list (see et_set_update_op for the meaning of a
+ * row; a later entry for the same (from, to) replaces an earlier one, eigentrust/src/lib.rs:415).
+ * member: n flags or NULL (= every slot holds a peer).  Exactly one of value_u32 / value_fr. */
+int et_graph_build(uint32_t n, const uint8_t *member, uint64_t n_edges, const uint32_t *from,
+                   const uint32_t *to, const uint32_t *value_u32, const et_fr *value_fr,
+                   const et_build_opts *opts, et_graph **out);
+void et_graph_free(et_graph *g);
+int et_graph_info_get(const et_graph *g, et_graph_info *info);
+
+/* Whole converge on this graph (n_seg must be 1): scores for all n slots in slot order. */
+int et_graph_converge_fr(et_graph *g, uint32_t num_iterations, uint64_t initial_lo,
+                         uint64_t initial_hi, et_fr *out);
+int et_graph_converge_f64(et_graph *g, uint32_t num_iterations, double initial, double alpha,
+                          const double *pretrust, double *out, double *residual_l1);
+
+/* ---- device-resident stepping (benches, the sharded multi-GPU driver) ------------------------
+ * Trust vectors are device buffers of vec_len entries in position order (et_fr = 32 bytes, or
+ * double), allocated by the caller.  `stream` is a hipStream_t (NULL = default stream).  These
+ * calls only enqueue work and allocate nothing. */
+
+/* Writes this share's segment of the initial vector (INITIAL_SCORE for members, native.rs:184,317)
+ * plus its partial sums into x; other segments are left untouched (all-gather them). */
+int et_graph_init_fr_async(et_graph *g, uint64_t initial_lo, uint64_t initial_hi, void *x, void *stream);
+int et_graph_init_f64_async(et_graph *g, double initial, void *x, void *stream);
+/* One iteration (native.rs:320-328 for every row of this share): reads all of x, writes this
+ * share's segment of y.  `iteration` selects the slot of the per-iteration statistics.
+ * pretrust_pos: device doubles in position order, or NULL. */
+int et_graph_step_fr_async(et_graph *g, const void *x, void *y, uint32_t iteration, void *stream);
+int et_graph_step_f64_async(et_graph *g, const void *x, void *y, uint32_t iteration, double alpha,
+                            const void *pretrust_pos, void *stream);
+/* Position order -> slot order (device to device): out has n entries. */
+int et_graph_unpermute_fr_async(et_graph *g, const void *x, void *out_slots, void *stream);
+int et_graph_unpermute_f64_async(et_graph *g, const void *x, void *out_slots, void *stream);
+/* Slot order -> position order for a host vector of doubles (pretrust); fills vec_len entries. */
+int et_graph_permute_f64_host(const et_graph *g, const double *slots, double *pos);
+
+typedef struct {
+    et_fr sum;              /* field sum of this share's new scores (conservation, native.rs:333) */
+    uint64_t changed;       /* rows of this share whose score changed in that iteration           */
+    double residual_l1;     /* f64: sum |new - old| over this share                               */
+    double sum_f64;         /* f64: sum of this share's new scores                                */
+} et_iter_stats;
+/* Reduces the per-workgroup statistics of `iteration` (synchronises the stream). */
+int et_graph_stats_fr(et_graph *g, uint32_t iteration, void *stream, et_iter_stats *out);
+int et_graph_stats_f64(et_graph *g, uint32_t iteration, void *stream, et_iter_stats *out);
+
+/* Runs init + num_iterations steps + unpermute back to back on `stream` with the graph's own
+ * double-buffered vectors (n_seg must be 1); leaves the slot-order result on the device.  When
+ * step_ms is not NULL the iteration launches are bracketed by HIP events and the elapsed time of
+ * the num_iterations launches is returned (this synchronises the stream). */
+int et_graph_run_fr(et_graph *g, uint32_t num_iterations, uint64_t initial_lo, uint64_t initial_hi,
+                    void *stream, float *step_ms);
+int et_graph_run_f64(et_graph *g, uint32_t num_iterations, double initial, double alpha,
+                     void *stream, float *step_ms);
+/* Copies the result of the last et_graph_run_* to the host (n entries, slot order). */
+int et_graph_result_fr(et_graph *g, et_fr *out, void *stream);
+int et_graph_result_f64(et_graph *g, double *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Deterministic synthetic attestation lists (benchmarks and parity tests use the same inputs).
+ * kind: 2 = uniform out-degree, 3 = power-law out-degree with preferential targets and a share of
+ * peers without opinions.  Two-call protocol: with from == NULL only *n_edges is written.
+ * ---------------------------------------------------------------------------------------- */
+int et_synth_graph(uint32_t kind, uint32_t n, uint64_t target_edges, uint64_t seed,
+                   uint32_t value_max, uint64_t *n_edges, uint32_t *from, uint32_t *to,
+                   uint32_t *value);
+
+/* Field arithmetic self-test hook: runs the device multiply-accumulate + reduction used by the
+ * Fr kernel on `count` (a, b) pairs and returns a[i]*b[i] mod r (canonical in, canonical out). */
+int et_dev_fr_mul(uint32_t count, const et_fr *a, const et_fr *b, et_fr *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EIGENTRUST_HIP_H */

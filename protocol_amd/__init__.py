@@ -1,0 +1,9 @@
+"""MI355X-native EigenTrust convergence engine (HIP kernels behind a C ABI).
+
+`EigenTrustSet` mirrors the reference's set API; `Graph` exposes the device-resident engine.
+Everything computes on the GPU through protocol_amd/lib/libeigentrust_hip.so; there is no CPU path.
+"""
+from ._ffi import EigenTrustError, LIB_PATH, lib  # noqa: F401
+from .eigentrust_set import (EigenTrustSet, INITIAL_SCORE, MIN_PEER_COUNT, NUM_ITERATIONS,  # noqa: F401
+                             NUM_NEIGHBOURS)
+from .graph import Graph, R_MODULUS, fr_bytes_from_ints, fr_ints_from_bytes, synth_graph  # noqa: F401

@@ -1,0 +1,124 @@
+"""ctypes binding of protocol_amd/lib/libeigentrust_hip.so (C ABI: include/eigentrust_hip.h).
+
+The library is the product; this module only declares its entry points.  There is no fallback:
+if the shared object is missing, importing the compute classes raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libeigentrust_hip.so")
+
+ET_OK = 0
+ET_E_DUP_MEMBER = -1
+ET_E_SET_FULL = -2
+ET_E_NOT_MEMBER = -3
+ET_E_INSUFFICIENT_PEERS = -4
+ET_E_SUM_MISMATCH = -5
+ET_E_NONCANONICAL_FR = -6
+ET_E_INVALID_ARG = -7
+ET_E_HIP = -8
+ET_E_NO_DEVICE = -9
+ET_E_BUFFER_TOO_SMALL = -10
+ET_E_OUT_OF_RANGE = -11
+ET_E_UNSUPPORTED = -12
+
+ET_VARIANT_FR = 1
+ET_VARIANT_F64 = 2
+
+
+class EtFr(C.Structure):
+    _fields_ = [("b", C.c_uint8 * 32)]
+
+
+class EtBuildOpts(C.Structure):
+    _fields_ = [("n_seg", C.c_uint32), ("seg", C.c_uint32), ("long_row", C.c_uint32),
+                ("target_blocks", C.c_uint32), ("variants", C.c_uint32), ("device", C.c_int32)]
+
+
+class EtGraphInfo(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("n_valid", C.c_uint32), ("n_dangling", C.c_uint32),
+                ("n_seg", C.c_uint32), ("seg", C.c_uint32),
+                ("nnz", C.c_uint64), ("nnz_local", C.c_uint64), ("padded_local", C.c_uint64),
+                ("n_slices", C.c_uint32), ("n_blocks", C.c_uint32),
+                ("rows_cap", C.c_uint32), ("nd_cap", C.c_uint32),
+                ("vec_len", C.c_uint64), ("device_bytes", C.c_uint64)]
+
+
+class EtIterStats(C.Structure):
+    _fields_ = [("sum", EtFr), ("changed", C.c_uint64), ("residual_l1", C.c_double),
+                ("sum_f64", C.c_double)]
+
+
+# every symbol include/eigentrust_hip.h declares, with its prototype
+vp, u32, u64, i32, dbl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
+P = C.POINTER
+PROTOTYPES = {
+    "et_strerror": (C.c_char_p, [i32]),
+    "et_last_error_message": (C.c_char_p, []),
+    "et_abi_version": (u32, []),
+    "et_device_count": (i32, []),
+    "et_set_new": (i32, [u32, u32, u64, u64, vp, P(vp)]),
+    "et_set_free": (None, [vp]),
+    "et_set_add_member": (i32, [vp, vp]),
+    "et_set_remove_member": (i32, [vp, vp]),
+    "et_set_update_op": (i32, [vp, vp, vp]),
+    "et_set_update_op_sparse": (i32, [vp, vp, u32, vp, vp]),
+    "et_set_update_op_u32": (i32, [vp, u32, u32, vp, vp]),
+    "et_set_members": (i32, [vp, vp, vp]),
+    "et_set_converge": (i32, [vp, vp]),
+    "et_set_converge_f64": (i32, [vp, dbl, vp, vp, P(dbl)]),
+    "et_set_converge_rational": (i32, [vp, vp, vp, C.c_size_t, P(C.c_size_t)]),
+    "et_graph_build": (i32, [u32, vp, u64, vp, vp, vp, vp, P(EtBuildOpts), P(vp)]),
+    "et_graph_free": (None, [vp]),
+    "et_graph_info_get": (i32, [vp, P(EtGraphInfo)]),
+    "et_graph_converge_fr": (i32, [vp, u32, u64, u64, vp]),
+    "et_graph_converge_f64": (i32, [vp, u32, dbl, dbl, vp, vp, P(dbl)]),
+    "et_graph_init_fr_async": (i32, [vp, u64, u64, vp, vp]),
+    "et_graph_init_f64_async": (i32, [vp, dbl, vp, vp]),
+    "et_graph_step_fr_async": (i32, [vp, vp, vp, u32, vp]),
+    "et_graph_step_f64_async": (i32, [vp, vp, vp, u32, dbl, vp, vp]),
+    "et_graph_unpermute_fr_async": (i32, [vp, vp, vp, vp]),
+    "et_graph_unpermute_f64_async": (i32, [vp, vp, vp, vp]),
+    "et_graph_permute_f64_host": (i32, [vp, vp, vp]),
+    "et_graph_stats_fr": (i32, [vp, u32, vp, P(EtIterStats)]),
+    "et_graph_stats_f64": (i32, [vp, u32, vp, P(EtIterStats)]),
+    "et_graph_run_fr": (i32, [vp, u32, u64, u64, vp, P(C.c_float)]),
+    "et_graph_run_f64": (i32, [vp, u32, dbl, dbl, vp, P(C.c_float)]),
+    "et_graph_result_fr": (i32, [vp, vp, vp]),
+    "et_graph_result_f64": (i32, [vp, vp, vp]),
+    "et_synth_graph": (i32, [u32, u32, u64, u64, u32, P(u64), vp, vp, vp]),
+    "et_dev_fr_mul": (i32, [u32, vp, vp, vp]),
+}
+
+_lib = None
+
+
+class EigenTrustError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = lib().et_strerror(code).decode()
+        if detail:
+            msg += " (" + detail + ")"
+        super().__init__("[%d] %s" % (code, msg))
+
+
+def lib():
+    """Loads the shared library; raises if it was not built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libeigentrust_hip.so not found at %s; run `make -C protocol_amd/csrc` "
+                              "(or __graft_entry__.build())" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != ET_OK:
+        raise EigenTrustError(rc, lib().et_last_error_message().decode(errors="replace"))

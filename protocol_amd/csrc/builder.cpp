@@ -1,0 +1,318 @@
+#include "builder.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "../../include/eigentrust_hip.h"
+
+namespace et {
+
+namespace {
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return m == 0 ? v : (v + m - 1) / m * m; }
+
+struct Pos {  // global sorted row -> (segment, local row, position)
+    uint32_t n_seg, stride;
+    inline uint32_t seg_of(uint32_t q) const { return (q >> 6) % n_seg; }
+    inline uint32_t local_of(uint32_t q) const { return ((q >> 6) / n_seg) * 64 + (q & 63); }
+    inline uint32_t pos_of(uint32_t q) const { return seg_of(q) * stride + local_of(q); }
+};
+
+}  // namespace
+
+int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::string& err) {
+    const uint32_t n = in.n;
+    if (n == 0 || (in.n_edges && (!in.from || !in.to)) || ((in.val_u32 != nullptr) == (in.val_fr != nullptr) && in.n_edges)) {
+        err = "bad build input";
+        return ET_E_INVALID_ARG;
+    }
+    if (opt.n_seg == 0 || opt.seg >= opt.n_seg) {
+        err = "bad segment";
+        return ET_E_INVALID_ARG;
+    }
+    g = HostGraph();
+    g.n = n;
+    g.values_are_u32 = in.val_fr == nullptr;
+    auto is_member = [&](uint32_t i) { return in.member ? in.member[i] != 0 : true; };
+    uint32_t n_valid = 0;
+    for (uint32_t i = 0; i < n; ++i) n_valid += is_member(i);
+    g.n_valid = n_valid;
+    if (n_valid < 2) {  // native.rs:288-289
+        err = "Insufficient peers for calculation!";
+        return ET_E_INSUFFICIENT_PEERS;
+    }
+
+    // ---- 1. filter (native.rs:248-260) and group by attester --------------------------------
+    const uint64_t ne = in.n_edges;
+    std::vector<uint64_t> out_ptr((size_t)n + 1, 0);
+    for (uint64_t e = 0; e < ne; ++e) {
+        uint32_t f = in.from[e], t = in.to[e];
+        if (f >= n || t >= n) {
+            err = "edge endpoint out of range";
+            return ET_E_OUT_OF_RANGE;
+        }
+        if (f == t || !is_member(f) || !is_member(t)) continue;
+        out_ptr[f + 1]++;
+    }
+    for (uint32_t i = 0; i < n; ++i) out_ptr[i + 1] += out_ptr[i];
+    const uint64_t m0 = out_ptr[n];
+    // kept[k] = original edge index, grouped by attester, original order inside a group
+    std::vector<uint64_t> kept(m0);
+    {
+        std::vector<uint64_t> cur(out_ptr.begin(), out_ptr.end() - 1);
+        for (uint64_t e = 0; e < ne; ++e) {
+            uint32_t f = in.from[e], t = in.to[e];
+            if (f == t || !is_member(f) || !is_member(t)) continue;
+            kept[cur[f]++] = e;
+        }
+    }
+    // ---- 2. inside each attester: order by rated peer, last write wins (lib.rs:415) ---------
+    std::vector<uint8_t> drop(m0, 0);
+    for (uint32_t f = 0; f < n; ++f) {
+        uint64_t b = out_ptr[f], e = out_ptr[f + 1];
+        if (e - b < 2) continue;
+        bool sorted_unique = true;
+        for (uint64_t k = b + 1; k < e; ++k)
+            if (in.to[kept[k - 1]] >= in.to[kept[k]]) { sorted_unique = false; break; }
+        if (sorted_unique) continue;
+        std::stable_sort(kept.begin() + b, kept.begin() + e, [&](uint64_t x, uint64_t y) { return in.to[x] < in.to[y]; });
+        for (uint64_t k = b; k + 1 < e; ++k)
+            if (in.to[kept[k]] == in.to[kept[k + 1]]) drop[k] = 1;  // an equal later one follows
+    }
+    // ---- 3. row sums: in the field (dangling test, native.rs:263-264) and as integers -------
+    std::vector<Fr> sum_fr;
+    std::vector<uint64_t> sum_u64;
+    std::vector<long double> sum_ld;
+    if (g.values_are_u32) sum_u64.assign(n, 0);
+    else { sum_fr.assign(n, Fr::zero()); sum_ld.assign(n, 0.0L); }
+    for (uint32_t f = 0; f < n; ++f) {
+        for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
+            if (drop[k]) continue;
+            uint64_t e = kept[k];
+            if (g.values_are_u32) sum_u64[f] += in.val_u32[e];
+            else {
+                const FrRaw& v = in.val_fr[e];
+                if (!fr_raw_is_canonical(v.l)) {
+                    err = "opinion value is not a canonical field element";
+                    return ET_E_NONCANONICAL_FR;
+                }
+                sum_fr[f] += Fr::from_raw(v);
+                sum_ld[f] += (long double)v.l[0] + 18446744073709551616.0L * ((long double)v.l[1] + 18446744073709551616.0L * ((long double)v.l[2] + 18446744073709551616.0L * (long double)v.l[3]));
+            }
+        }
+    }
+    std::vector<uint8_t> dangling(n, 0);
+    uint32_t n_dangling = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!is_member(i)) continue;
+        bool zero = g.values_are_u32 ? sum_u64[i] == 0 : sum_fr[i].is_zero();
+        if (zero) { dangling[i] = 1; ++n_dangling; }
+    }
+    // ---- 4. degrees over surviving edges -----------------------------------------------------
+    std::vector<uint32_t> in_deg(n, 0), out_deg(n, 0);
+    uint64_t nnz = 0;
+    for (uint32_t f = 0; f < n; ++f) {
+        if (dangling[f]) continue;
+        for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
+            if (drop[k]) continue;
+            in_deg[in.to[kept[k]]]++;
+            out_deg[f]++;
+            ++nnz;
+        }
+    }
+    g.nnz = nnz;
+    // ---- 5. global row order: active peers by in-degree (desc), then dangling peers ----------
+    const uint32_t n_active = n_valid - n_dangling;
+    std::vector<uint32_t> order;
+    order.reserve(n_valid);
+    for (uint32_t i = 0; i < n; ++i) if (is_member(i) && !dangling[i]) order.push_back(i);
+    for (uint32_t i = 0; i < n; ++i) if (is_member(i) && dangling[i]) order.push_back(i);
+    auto by_deg = [&](uint32_t a, uint32_t b) {
+        if (in_deg[a] != in_deg[b]) return in_deg[a] > in_deg[b];
+        if (out_deg[a] != out_deg[b]) return out_deg[a] > out_deg[b];
+        return a < b;
+    };
+    std::sort(order.begin(), order.begin() + n_active, by_deg);
+    std::sort(order.begin() + n_active, order.end(), by_deg);
+
+    const uint32_t G = opt.n_seg;
+    Geometry geo{};
+    geo.n_seg = G;
+    geo.seg = opt.seg;
+    geo.n_active = n_active;
+    geo.n_active_pad = round_up(n_active, 64 * G);
+    geo.n_dangling = n_dangling;
+    geo.n_dangling_pad = round_up(n_dangling, 64 * G);
+    geo.rows_cap = (geo.n_active_pad + geo.n_dangling_pad) / G;
+    geo.nd_cap = opt.nd_cap ? opt.nd_cap : 32;
+    g.geo = geo;
+    if ((uint64_t)G * geo.seg_stride() >= 0xFFFFFFFFull) {
+        err = "position space exceeds 32 bits";
+        return ET_E_UNSUPPORTED;
+    }
+    Pos P{G, geo.seg_stride()};
+    // q (global sorted row incl. class padding) of the i-th entry of `order`
+    auto q_of_rank = [&](uint32_t r) { return r < n_active ? r : geo.n_active_pad + (r - n_active); };
+    g.pos_of_ext.assign(n, 0xFFFFFFFFu);
+    for (uint32_t r = 0; r < n_valid; ++r) g.pos_of_ext[order[r]] = P.pos_of(q_of_rank(r));
+
+    // ---- 6. per-position source factors ------------------------------------------------------
+    const size_t vec_len = (size_t)G * geo.seg_stride();
+    g.scale_fr.assign(vec_len, FrRaw{{0, 0, 0, 0}});
+    g.scale_f64.assign(vec_len, 0.0);
+    {
+        std::vector<Fr> inv(n_active);
+        for (uint32_t r = 0; r < n_active; ++r) {
+            uint32_t i = order[r];
+            inv[r] = g.values_are_u32 ? Fr::from_u64(sum_u64[i]) : sum_fr[i];
+        }
+        fr_batch_invert(inv);  // native.rs:308
+        const Fr two576 = Fr::one().pow2k(576);
+        for (uint32_t r = 0; r < n_active; ++r) {
+            uint32_t i = order[r];
+            uint32_t p = g.pos_of_ext[i];
+            g.scale_fr[p] = (inv[r] * two576).to_raw();
+            g.scale_f64[p] = g.values_are_u32 ? 1.0 / (double)sum_u64[i] : (double)(1.0L / sum_ld[i]);
+        }
+        g.inv_nm1_w = (Fr::from_u64(n_valid - 1).invert_or_zero() * Fr::one().pow2k(288)).to_raw();
+    }
+
+    // ---- 7. in-edges of this segment's rows, sources ascending by position -------------------
+    // local row of an external peer, or ~0 when it lives in another segment
+    const uint32_t my_base = opt.seg * geo.seg_stride();
+    auto local_row = [&](uint32_t ext) -> uint32_t {
+        uint32_t p = g.pos_of_ext[ext];
+        if (p < my_base || p >= my_base + geo.rows_cap) return 0xFFFFFFFFu;
+        return p - my_base;
+    };
+    std::vector<uint64_t> in_ptr((size_t)geo.rows_cap + 1, 0);
+    for (uint32_t f = 0; f < n; ++f) {
+        if (dangling[f]) continue;
+        for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
+            if (drop[k]) continue;
+            uint32_t lr = local_row(in.to[kept[k]]);
+            if (lr != 0xFFFFFFFFu) in_ptr[lr + 1]++;
+        }
+    }
+    for (uint32_t i = 0; i < geo.rows_cap; ++i) in_ptr[i + 1] += in_ptr[i];
+    g.nnz_local = in_ptr[geo.rows_cap];
+    std::vector<uint32_t> e_src(g.nnz_local);   // source position
+    std::vector<uint64_t> e_idx(g.nnz_local);   // original edge index (for the value)
+    {
+        // visit attesters in ascending POSITION so that every row's sources come out sorted
+        std::vector<uint64_t> cur(in_ptr.begin(), in_ptr.end() - 1);
+        std::vector<uint32_t> by_pos(order.begin(), order.begin() + n_active);
+        std::sort(by_pos.begin(), by_pos.end(), [&](uint32_t a, uint32_t b) { return g.pos_of_ext[a] < g.pos_of_ext[b]; });
+        for (uint32_t f : by_pos) {
+            uint32_t pf = g.pos_of_ext[f];
+            for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
+                if (drop[k]) continue;
+                uint32_t lr = local_row(in.to[kept[k]]);
+                if (lr == 0xFFFFFFFFu) continue;
+                uint64_t p = cur[lr]++;
+                e_src[p] = pf;
+                e_idx[p] = kept[k];
+            }
+        }
+    }
+    // ---- 8. slices -----------------------------------------------------------------------------
+    const uint32_t long_row = opt.long_row ? opt.long_row : 128;
+    const uint32_t n_local_slices = geo.rows_cap / 64;
+    const uint32_t active_local_slices = geo.n_active_pad / 64 / G;
+    std::vector<uint8_t> slice_dangling;
+    uint64_t steps = 0;
+    auto real_rows_in_slice = [&](uint32_t ls) -> uint32_t {
+        uint64_t q0 = ((uint64_t)ls * G + opt.seg) * 64;  // global row of lane 0
+        uint64_t end = ls < active_local_slices ? n_active : (uint64_t)geo.n_active_pad + n_dangling;
+        if (q0 >= end) return 0;
+        return (uint32_t)std::min<uint64_t>(64, end - q0);
+    };
+    for (uint32_t ls = 0; ls < n_local_slices; ++ls) {
+        uint32_t nr = real_rows_in_slice(ls);
+        if (nr == 0) continue;
+        bool dang = ls >= active_local_slices;
+        uint32_t maxd = 0;
+        for (uint32_t l = 0; l < nr; ++l) maxd = std::max<uint32_t>(maxd, (uint32_t)(in_ptr[ls * 64 + l + 1] - in_ptr[ls * 64 + l]));
+        if (maxd > long_row) {
+            for (uint32_t l = 0; l < nr; ++l) {
+                uint32_t d = (uint32_t)(in_ptr[ls * 64 + l + 1] - in_ptr[ls * 64 + l]);
+                SliceDesc sd{(uint32_t)steps, (d + 63) / 64, ls * 64 + l, SLICE_REDUCE | 1u};
+                steps += sd.len;
+                g.slices.push_back(sd);
+                slice_dangling.push_back(dang);
+            }
+        } else {
+            SliceDesc sd{(uint32_t)steps, maxd, ls * 64, nr};
+            steps += maxd;
+            g.slices.push_back(sd);
+            slice_dangling.push_back(dang);
+        }
+        if (steps >= 0xFFFFFFFFull) {
+            err = "edge stream exceeds 2^32 steps";
+            return ET_E_UNSUPPORTED;
+        }
+    }
+    g.n_steps = steps;
+    g.n_dangling_local = 0;
+    for (uint32_t ls = active_local_slices; ls < n_local_slices; ++ls) g.n_dangling_local += real_rows_in_slice(ls);
+    // ---- 9. fill the edge stream -----------------------------------------------------------------
+    const size_t slots = (size_t)steps * 64;
+    g.col.assign(slots, 0);
+    if (g.values_are_u32) g.val_u32.assign(slots, 0);
+    else g.val_fr.assign(slots, FrRaw{{0, 0, 0, 0}});
+    for (const SliceDesc& sd : g.slices) {
+        if (sd.nrows & SLICE_REDUCE) {
+            uint64_t b = in_ptr[sd.row0], e = in_ptr[sd.row0 + 1];
+            for (uint64_t k = b; k < e; ++k) {
+                size_t slot = (size_t)sd.off * 64 + (k - b);  // lane = (k-b)%64, step = (k-b)/64
+                g.col[slot] = e_src[k];
+                if (g.values_are_u32) g.val_u32[slot] = in.val_u32[e_idx[k]];
+                else g.val_fr[slot] = in.val_fr[e_idx[k]];
+            }
+        } else {
+            for (uint32_t l = 0; l < sd.nrows; ++l) {
+                uint64_t b = in_ptr[sd.row0 + l], e = in_ptr[sd.row0 + l + 1];
+                for (uint64_t k = b; k < e; ++k) {
+                    size_t slot = ((size_t)sd.off + (k - b)) * 64 + l;
+                    g.col[slot] = e_src[k];
+                    if (g.values_are_u32) g.val_u32[slot] = in.val_u32[e_idx[k]];
+                    else g.val_fr[slot] = in.val_fr[e_idx[k]];
+                }
+            }
+        }
+    }
+    // ---- 10. workgroups: contiguous, class-pure, equal estimated cost ---------------------------
+    const uint32_t n_slices = (uint32_t)g.slices.size();
+    uint32_t first_dang = n_slices;
+    for (uint32_t s = 0; s < n_slices; ++s) if (slice_dangling[s]) { first_dang = s; break; }
+    auto cost = [&](uint32_t s) -> uint64_t { return (uint64_t)g.slices[s].len + 6; };
+    auto partition = [&](uint32_t sb, uint32_t se, uint32_t max_blocks, bool dang) {
+        if (sb >= se) return;
+        uint64_t total = 0;
+        for (uint32_t s = sb; s < se; ++s) total += cost(s);
+        uint32_t nb = std::max<uint32_t>(1, std::min<uint32_t>(max_blocks, (se - sb + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+        uint64_t per = (total + nb - 1) / nb;
+        uint32_t s = sb, dslot = 0;
+        while (s < se) {
+            uint64_t acc = 0;
+            uint32_t b = s;
+            while (s < se && (acc < per || s - b < 1)) acc += cost(s++);
+            // never leave more blocks than allowed: the last block takes the rest
+            if ((uint32_t)g.blocks.size() + 1 >= 0xFFFFFFF0u) break;
+            BlockDesc bd{b, s, dang ? BLOCK_DANGLING : 0u, dang ? dslot++ : 0u};
+            g.blocks.push_back(bd);
+        }
+    };
+    const uint32_t target = opt.target_blocks ? opt.target_blocks : 1024;
+    partition(0, first_dang, target, false);
+    size_t nb_active = g.blocks.size();
+    partition(first_dang, n_slices, geo.nd_cap, true);
+    if (g.blocks.size() - nb_active > geo.nd_cap) {
+        err = "internal: more dangling workgroups than partial-sum slots";
+        return ET_E_UNSUPPORTED;
+    }
+    return ET_OK;
+}
+
+}  // namespace et

@@ -1,0 +1,65 @@
+// Graph builder: attestation list -> filtered, transposed, sliced edge stream for one GPU.
+//
+// Implements, in sparse form, what the reference does densely before its iteration loop:
+//   * filter_peers_ops (dynamic_sets/native.rs:234-283): opinions about empty slots and about
+//     oneself are dropped; a peer whose remaining opinions sum to zero IN THE FIELD gives every
+//     other valid peer the opinion 1 ("dangling" here; evaluated by the kernels as a rank-1 term
+//     instead of materialising the row of ones);
+//   * the row sums and their inverses of native.rs:305-314 (the per-edge multiply is done on the GPU
+//     from the per-source factors computed here);
+//   * for the f64 variant the integer row sums of converge_rational (native.rs:367-377).
+// A later attestation for the same (from, to) pair replaces an earlier one, as
+// attestation_matrix[origin][dest] = Some(att) does in eigentrust/src/lib.rs:398-416.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "fr_host.hpp"
+#include "layout.hpp"
+
+namespace et {
+
+struct BuildInput {
+    uint32_t n = 0;                    // slots (peers incl. empty slots)
+    const uint8_t* member = nullptr;   // n flags, non-zero = slot holds a peer; nullptr = all members
+    uint64_t n_edges = 0;
+    const uint32_t* from = nullptr;    // attester slot
+    const uint32_t* to = nullptr;      // rated slot
+    const uint32_t* val_u32 = nullptr; // either small integer opinions ...
+    const FrRaw* val_fr = nullptr;     // ... or canonical field elements
+};
+
+struct BuildOpts {
+    uint32_t n_seg = 1;          // GPUs sharing the rows
+    uint32_t seg = 0;            // this GPU
+    uint32_t long_row = 128;     // in-degree above which a row is spread over a whole wavefront
+    uint32_t target_blocks = 1024;
+    uint32_t nd_cap = 32;        // partial-sum slots per segment (>= workgroups holding dangling rows)
+};
+
+struct HostGraph {
+    uint32_t n = 0;
+    uint32_t n_valid = 0;
+    uint64_t nnz = 0;            // surviving edges of non-dangling peers, all segments
+    uint64_t nnz_local = 0;      // ... whose destination row is in this segment
+    bool values_are_u32 = true;
+    Geometry geo{};
+    std::vector<uint32_t> pos_of_ext;   // n entries: position of each peer, 0xFFFFFFFF for empty slots
+    std::vector<SliceDesc> slices;
+    std::vector<BlockDesc> blocks;
+    uint64_t n_steps = 0;
+    std::vector<uint32_t> col;          // n_steps*64 source positions
+    std::vector<uint32_t> val_u32;      // n_steps*64 raw opinions (values_are_u32)
+    std::vector<FrRaw> val_fr;          // n_steps*64 raw opinions (!values_are_u32)
+    // Per-position source factors (zero for dangling / non-member / padding positions):
+    std::vector<FrRaw> scale_fr;        // inv(row sum) * 2^576 mod r
+    std::vector<double> scale_f64;      // 1 / integer row sum
+    FrRaw inv_nm1_w{};                  // inv(n_valid - 1) * 2^288 mod r
+    uint32_t n_dangling_local = 0;      // real dangling rows in this segment
+};
+
+// Returns 0 or a negative ET_E_* code; `err` receives a human-readable reason.
+int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& out, std::string& err);
+
+}  // namespace et

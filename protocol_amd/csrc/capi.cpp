@@ -1,0 +1,235 @@
+// extern "C" surface of the graph engine (declarations and contracts: include/eigentrust_hip.h).
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/eigentrust_hip.h"
+#include "builder.hpp"
+#include "engine.hpp"
+#include "fr_host.hpp"
+
+using namespace et;
+
+static inline DeviceGraph* G(et_graph* g) { return reinterpret_cast<DeviceGraph*>(g); }
+static inline const DeviceGraph* G(const et_graph* g) { return reinterpret_cast<const DeviceGraph*>(g); }
+
+#define HIP_TRY_C(expr)                                                              \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess) {                                                      \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));            \
+            return _e == hipErrorNoDevice ? ET_E_NO_DEVICE : ET_E_HIP;               \
+        }                                                                            \
+    } while (0)
+
+extern "C" {
+
+const char* et_strerror(int code) {
+    switch (code) {
+        case ET_OK: return "ok";
+        case ET_E_DUP_MEMBER: return "member already in the set";
+        case ET_E_SET_FULL: return "no empty slot left in the set";
+        case ET_E_NOT_MEMBER: return "address is not a member of the set";
+        case ET_E_INSUFFICIENT_PEERS: return "Insufficient peers for calculation!";
+        case ET_E_SUM_MISMATCH: return "sum of scores changed during convergence";
+        case ET_E_NONCANONICAL_FR: return "field element is not canonical (>= r)";
+        case ET_E_INVALID_ARG: return "invalid argument";
+        case ET_E_HIP: return "HIP runtime error";
+        case ET_E_NO_DEVICE: return "no HIP device available";
+        case ET_E_BUFFER_TOO_SMALL: return "output buffer too small";
+        case ET_E_OUT_OF_RANGE: return "index out of range";
+        case ET_E_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown error";
+    }
+}
+const char* et_last_error_message(void) { return last_error(); }
+uint32_t et_abi_version(void) { return (0u << 16) | 1u; }
+int et_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e == hipErrorNoDevice) return 0;
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return ET_E_HIP; }
+    return n;
+}
+
+int et_graph_build(uint32_t n, const uint8_t* member, uint64_t n_edges, const uint32_t* from, const uint32_t* to,
+                   const uint32_t* value_u32, const et_fr* value_fr, const et_build_opts* opts, et_graph** out) {
+    if (!out) return ET_E_INVALID_ARG;
+    BuildInput in;
+    in.n = n;
+    in.member = member;
+    in.n_edges = n_edges;
+    in.from = from;
+    in.to = to;
+    in.val_u32 = value_u32;
+    in.val_fr = reinterpret_cast<const FrRaw*>(value_fr);
+    static const uint32_t dummy32 = 0;
+    if (n_edges == 0 && !value_u32 && !value_fr) in.val_u32 = &dummy32;
+    BuildOpts bo;
+    int variants = 0, device = -1;
+    if (opts) {
+        if (opts->n_seg) bo.n_seg = opts->n_seg;
+        bo.seg = opts->seg;
+        if (opts->long_row) bo.long_row = opts->long_row;
+        if (opts->target_blocks) bo.target_blocks = opts->target_blocks;
+        variants = (int)opts->variants;
+        device = opts->device;
+    }
+    HostGraph h;
+    std::string err;
+    int rc = build_graph(in, bo, h, err);
+    if (rc) { set_error(err); return rc; }
+    DeviceGraph* dg = nullptr;
+    rc = DeviceGraph::create(h, variants, device, &dg);
+    if (rc) return rc;
+    *out = reinterpret_cast<et_graph*>(dg);
+    return ET_OK;
+}
+
+void et_graph_free(et_graph* g) { delete G(g); }
+
+int et_graph_info_get(const et_graph* g, et_graph_info* info) {
+    if (!g || !info) return ET_E_INVALID_ARG;
+    const DeviceGraph* d = G(g);
+    std::memset(info, 0, sizeof(*info));
+    info->n = d->n; info->n_valid = d->n_valid; info->n_dangling = d->geo.n_dangling;
+    info->n_seg = d->geo.n_seg; info->seg = d->geo.seg;
+    info->nnz = d->nnz; info->nnz_local = d->nnz_local; info->padded_local = d->n_steps * 64;
+    info->n_slices = d->n_slices; info->n_blocks = d->n_blocks;
+    info->rows_cap = d->geo.rows_cap; info->nd_cap = d->geo.nd_cap;
+    info->vec_len = d->vec_len; info->device_bytes = d->device_bytes;
+    return ET_OK;
+}
+
+int et_graph_converge_fr(et_graph* g, uint32_t num_iterations, uint64_t initial_lo, uint64_t initial_hi, et_fr* out) {
+    if (!g || !out) return ET_E_INVALID_ARG;
+    DeviceGraph* d = G(g);
+    HIP_TRY_C(hipSetDevice(d->device));
+    int rc = d->run_fr(num_iterations, initial_lo, initial_hi, nullptr, nullptr);
+    if (rc) return rc;
+    if ((rc = et_graph_result_fr(g, out, nullptr))) return rc;
+    // conservation (native.rs:331-334): sum of the initial scores == sum of the final scores
+    Fr expect = Fr::from_u128(initial_lo, initial_hi) * Fr::from_u64(d->n_valid);
+    if (num_iterations > 0) {
+        et_iter_stats st;
+        if ((rc = d->stats_fr(num_iterations - 1, nullptr, &st))) return rc;
+        FrRaw got;
+        std::memcpy(got.l, st.sum.b, 32);
+        if (got != expect.to_raw()) { set_error("reputation leak: field sum of scores changed"); return ET_E_SUM_MISMATCH; }
+    }
+    return ET_OK;
+}
+
+int et_graph_converge_f64(et_graph* g, uint32_t num_iterations, double initial, double alpha, const double* pretrust,
+                          double* out, double* residual_l1) {
+    if (!g || !out) return ET_E_INVALID_ARG;
+    DeviceGraph* d = G(g);
+    HIP_TRY_C(hipSetDevice(d->device));
+    if (d->geo.n_seg != 1) { set_error("converge needs the whole graph on one GPU"); return ET_E_UNSUPPORTED; }
+    int rc;
+    if (pretrust && alpha != 0.0) {
+        std::vector<double> pos(d->vec_len);
+        if ((rc = et_graph_permute_f64_host(g, pretrust, pos.data()))) return rc;
+        if (!d->d_pretrust) {
+            HIP_TRY_C(hipMalloc((void**)&d->d_pretrust, d->vec_len * sizeof(double)));
+            d->device_bytes += d->vec_len * sizeof(double);
+        }
+        HIP_TRY_C(hipMemcpy(d->d_pretrust, pos.data(), d->vec_len * sizeof(double), hipMemcpyHostToDevice));
+        if ((rc = d->init_f64(initial, d->vx[0], nullptr))) return rc;
+        for (uint32_t it = 0; it < num_iterations; ++it)
+            if ((rc = d->step_f64(d->vx[it & 1], d->vx[(it + 1) & 1], it, alpha, d->d_pretrust, nullptr))) return rc;
+        if ((rc = d->unpermute_f64(d->vx[num_iterations & 1], d->out_f64, nullptr))) return rc;
+    } else {
+        if ((rc = d->run_f64(num_iterations, initial, alpha, nullptr, nullptr))) return rc;
+    }
+    if ((rc = et_graph_result_f64(g, out, nullptr))) return rc;
+    if (residual_l1) {
+        *residual_l1 = 0.0;
+        if (num_iterations > 0) {
+            et_iter_stats st;
+            if ((rc = d->stats_f64(num_iterations - 1, nullptr, &st))) return rc;
+            *residual_l1 = st.residual_l1;
+        }
+    }
+    return ET_OK;
+}
+
+int et_graph_init_fr_async(et_graph* g, uint64_t lo, uint64_t hi, void* x, void* stream) {
+    if (!g || !x) return ET_E_INVALID_ARG;
+    return G(g)->init_fr(lo, hi, (uint4*)x, (hipStream_t)stream);
+}
+int et_graph_init_f64_async(et_graph* g, double initial, void* x, void* stream) {
+    if (!g || !x) return ET_E_INVALID_ARG;
+    return G(g)->init_f64(initial, (double*)x, (hipStream_t)stream);
+}
+int et_graph_step_fr_async(et_graph* g, const void* x, void* y, uint32_t iteration, void* stream) {
+    if (!g || !x || !y) return ET_E_INVALID_ARG;
+    return G(g)->step_fr((const uint4*)x, (uint4*)y, iteration, (hipStream_t)stream);
+}
+int et_graph_step_f64_async(et_graph* g, const void* x, void* y, uint32_t iteration, double alpha,
+                            const void* pretrust_pos, void* stream) {
+    if (!g || !x || !y) return ET_E_INVALID_ARG;
+    return G(g)->step_f64((const double*)x, (double*)y, iteration, alpha, (const double*)pretrust_pos, (hipStream_t)stream);
+}
+int et_graph_unpermute_fr_async(et_graph* g, const void* x, void* out_slots, void* stream) {
+    if (!g || !x || !out_slots) return ET_E_INVALID_ARG;
+    return G(g)->unpermute_fr((const uint4*)x, (uint4*)out_slots, (hipStream_t)stream);
+}
+int et_graph_unpermute_f64_async(et_graph* g, const void* x, void* out_slots, void* stream) {
+    if (!g || !x || !out_slots) return ET_E_INVALID_ARG;
+    return G(g)->unpermute_f64((const double*)x, (double*)out_slots, (hipStream_t)stream);
+}
+int et_graph_permute_f64_host(const et_graph* g, const double* slots, double* pos) {
+    if (!g || !slots || !pos) return ET_E_INVALID_ARG;
+    const DeviceGraph* d = G(g);
+    std::memset(pos, 0, d->vec_len * sizeof(double));
+    for (uint32_t i = 0; i < d->n; ++i)
+        if (d->pos_of_ext[i] != 0xFFFFFFFFu) pos[d->pos_of_ext[i]] = slots[i];
+    return ET_OK;
+}
+int et_graph_stats_fr(et_graph* g, uint32_t iteration, void* stream, et_iter_stats* out) {
+    if (!g || !out) return ET_E_INVALID_ARG;
+    return G(g)->stats_fr(iteration, (hipStream_t)stream, out);
+}
+int et_graph_stats_f64(et_graph* g, uint32_t iteration, void* stream, et_iter_stats* out) {
+    if (!g || !out) return ET_E_INVALID_ARG;
+    return G(g)->stats_f64(iteration, (hipStream_t)stream, out);
+}
+int et_graph_run_fr(et_graph* g, uint32_t num_iterations, uint64_t lo, uint64_t hi, void* stream, float* step_ms) {
+    if (!g) return ET_E_INVALID_ARG;
+    return G(g)->run_fr(num_iterations, lo, hi, (hipStream_t)stream, step_ms);
+}
+int et_graph_run_f64(et_graph* g, uint32_t num_iterations, double initial, double alpha, void* stream, float* step_ms) {
+    if (!g) return ET_E_INVALID_ARG;
+    return G(g)->run_f64(num_iterations, initial, alpha, (hipStream_t)stream, step_ms);
+}
+int et_graph_result_fr(et_graph* g, et_fr* out, void* stream) {
+    if (!g || !out) return ET_E_INVALID_ARG;
+    DeviceGraph* d = G(g);
+    if (!d->out_fr) return ET_E_UNSUPPORTED;
+    HIP_TRY_C(hipMemcpyAsync(out, d->out_fr, (size_t)d->n * 32, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY_C(hipStreamSynchronize((hipStream_t)stream));
+    return ET_OK;
+}
+int et_graph_result_f64(et_graph* g, double* out, void* stream) {
+    if (!g || !out) return ET_E_INVALID_ARG;
+    DeviceGraph* d = G(g);
+    if (!d->out_f64) return ET_E_UNSUPPORTED;
+    HIP_TRY_C(hipMemcpyAsync(out, d->out_f64, (size_t)d->n * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY_C(hipStreamSynchronize((hipStream_t)stream));
+    return ET_OK;
+}
+
+int et_dev_fr_mul(uint32_t count, const et_fr* a, const et_fr* b, et_fr* out) {
+    if (count && (!a || !b || !out)) return ET_E_INVALID_ARG;
+    for (uint32_t i = 0; i < count; ++i) {
+        FrRaw x, y;
+        std::memcpy(x.l, a[i].b, 32);
+        std::memcpy(y.l, b[i].b, 32);
+        if (!fr_raw_is_canonical(x.l) || !fr_raw_is_canonical(y.l)) return ET_E_NONCANONICAL_FR;
+    }
+    return dev_fr_mul(count, a, b, out);
+}
+
+}  // extern "C"

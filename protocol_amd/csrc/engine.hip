@@ -1,0 +1,678 @@
+// GPU engine: upload of a prepared graph, on-device normalisation, the per-iteration kernels.
+//
+// One launch per iteration (dynamic_sets/native.rs:319-329).  Each launch fuses, per destination
+// row i:   new_s[i] = sum_j c_ji * s[j]                    (native.rs:320-326)
+//                   + (D - dangling_i * s[i]) / (n_valid-1)  (the rows of ones of native.rs:263-278)
+//          [f64 only] new_s[i] = (1-alpha) * new_s[i] + alpha * p[i]
+// and the reductions the next launch / the caller need: the score mass D' of dangling peers, the
+// sum of scores (conservation check, native.rs:331-334), and the residual (f64: L1 distance,
+// Fr: number of changed rows).  Reductions are per-workgroup partial results combined in a fixed
+// order, so every run and every GPU count produces identical bits.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/eigentrust_hip.h"
+#include "builder.hpp"
+#include "engine.hpp"
+#include "fr_dev.hpp"
+
+namespace et {
+
+thread_local std::string g_last_error;
+
+void set_error(const std::string& s) { g_last_error = s; }
+const char* last_error() { return g_last_error.c_str(); }
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                     \
+            return _e == hipErrorNoDevice ? ET_E_NO_DEVICE : ET_E_HIP;                        \
+        }                                                                                     \
+    } while (0)
+
+static const uint32_t STATS_RING = 64;
+
+// ---------------------------------------------------------------------------------------------
+// kernels: normalisation (native.rs:305-314, once per graph)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_normalise_f64_u32(const uint32_t* __restrict__ col, const uint32_t* __restrict__ val,
+                                    const double* __restrict__ scale, double* __restrict__ w, size_t slots) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < slots) w[i] = (double)val[i] * scale[col[i]];
+}
+__global__ void k_normalise_f64_fr(const uint32_t* __restrict__ col, const uint4* __restrict__ val,
+                                   const double* __restrict__ scale, double* __restrict__ w, size_t slots) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slots) return;
+    U256 v = u256_load(val + 2 * i);
+    double d = 0.0;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) d = d * 4294967296.0 + (double)v.v[k];
+    w[i] = d * scale[col[i]];
+}
+__global__ void k_normalise_fr_u32(const uint32_t* __restrict__ col, const uint32_t* __restrict__ val,
+                                   const uint4* __restrict__ scale, uint4* __restrict__ wlo,
+                                   uint4* __restrict__ whi, size_t slots) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slots) return;
+    U256 k = u256_load(scale + 2 * (size_t)col[i]);
+    Acc a = acc_zero();
+    acc_mac_u32(a, k, val[i]);
+    U256 w = acc_redc288(a);  // v * inv(sum) * 2^576 * 2^-288 = weight * 2^288
+    wlo[i] = make_uint4(w.v[0], w.v[1], w.v[2], w.v[3]);
+    whi[i] = make_uint4(w.v[4], w.v[5], w.v[6], w.v[7]);
+}
+__global__ void k_normalise_fr_fr(const uint32_t* __restrict__ col, const uint4* __restrict__ val,
+                                  const uint4* __restrict__ scale, uint4* __restrict__ wlo,
+                                  uint4* __restrict__ whi, size_t slots) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slots) return;
+    U256 k = u256_load(scale + 2 * (size_t)col[i]);
+    U256 v = u256_load(val + 2 * i);
+    Acc a = acc_zero();
+    acc_mac(a, k, v);
+    U256 w = acc_redc288(a);
+    wlo[i] = make_uint4(w.v[0], w.v[1], w.v[2], w.v[3]);
+    whi[i] = make_uint4(w.v[4], w.v[5], w.v[6], w.v[7]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels: initial vector (native.rs:184-185, :317).  Writes this segment only.
+// ---------------------------------------------------------------------------------------------
+ET_DEV bool row_is_member(const Geometry& g, uint32_t local) {
+    uint64_t q = ((uint64_t)(local >> 6) * g.n_seg + g.seg) * 64 + (local & 63);
+    return q < g.n_active || (q >= g.n_active_pad && q < (uint64_t)g.n_active_pad + g.n_dangling);
+}
+__global__ void k_init_f64(Geometry g, double initial, double d0, double* __restrict__ x) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t stride = g.seg_stride();
+    if (i >= stride) return;
+    double v = 0.0;
+    if (i < g.rows_cap) v = row_is_member(g, i) ? initial : 0.0;
+    else if (i == g.rows_cap) v = d0;
+    x[(size_t)g.seg * stride + i] = v;
+}
+__global__ void k_init_fr(Geometry g, U256 initial, U256 d0, uint4* __restrict__ x) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t stride = g.seg_stride();
+    if (i >= stride) return;
+    U256 v = u256_zero();
+    if (i < g.rows_cap) { if (row_is_member(g, i)) v = initial; }
+    else if (i == g.rows_cap) v = d0;
+    u256_store(x + 2 * ((size_t)g.seg * stride + i), v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels: one iteration
+// ---------------------------------------------------------------------------------------------
+struct StepArgsF64 {
+    const BlockDesc* blocks;
+    const SliceDesc* slices;
+    const uint32_t* col;
+    const double* w;
+    const double* x;
+    double* y;
+    const double* pretrust;  // position order, may be null
+    double* res_part;        // [n_blocks] of this iteration
+    double* sum_part;
+    Geometry geo;
+    double inv_nm1;
+    double alpha;
+};
+
+ET_DEV double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <bool HAS_ALPHA>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_step_f64(StepArgsF64 a) {
+    __shared__ double red[3][WAVES_PER_BLOCK];
+    const BlockDesc bd = a.blocks[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t stride = a.geo.seg_stride();
+    const size_t my_base = (size_t)a.geo.seg * stride;
+    const bool dang = (bd.flags & BLOCK_DANGLING) != 0;
+
+    // score mass of dangling peers: fixed-order sum of every segment's partial sums
+    double D = 0.0;
+    {
+        const uint32_t total = a.geo.n_seg * a.geo.nd_cap;
+        for (uint32_t t = lane; t < total; t += 64) {
+            uint32_t sg = t / a.geo.nd_cap, k = t - sg * a.geo.nd_cap;
+            D += a.x[(size_t)sg * stride + a.geo.rows_cap + k];
+        }
+        D = wave_sum_f64(D);
+    }
+    const double dterm = D * a.inv_nm1;
+
+    double res = 0.0, tot = 0.0, dacc = 0.0;
+    for (uint32_t s = bd.slice_begin + wave; s < bd.slice_end; s += WAVES_PER_BLOCK) {
+        const SliceDesc sd = a.slices[s];
+        const uint32_t* __restrict__ cp = a.col + (size_t)sd.off * 64 + lane;
+        const double* __restrict__ wp = a.w + (size_t)sd.off * 64 + lane;
+        double acc = 0.0;
+#pragma unroll 4
+        for (uint32_t k = 0; k < sd.len; ++k) {
+            uint32_t c = cp[(size_t)k * 64];
+            double w = wp[(size_t)k * 64];
+            acc = fma(w, a.x[c], acc);
+        }
+        const bool reduce = (sd.nrows & SLICE_REDUCE) != 0;
+        if (reduce) acc = wave_sum_f64(acc);
+        const uint32_t row = reduce ? sd.row0 : sd.row0 + lane;
+        const bool live = reduce ? lane == 0 : (uint32_t)lane < (sd.nrows & 0xFFu);
+        if (live) {
+            double old = a.x[my_base + row];
+            double v = dang ? acc + (D - old) * a.inv_nm1 : acc + dterm;
+            if (HAS_ALPHA) {
+                double p = a.pretrust[my_base + row];
+                v = (1.0 - a.alpha) * v + a.alpha * p;
+            }
+            a.y[my_base + row] = v;
+            res += fabs(v - old);
+            tot += v;
+            if (dang) dacc += v;
+        }
+    }
+    res = wave_sum_f64(res);
+    tot = wave_sum_f64(tot);
+    dacc = wave_sum_f64(dacc);
+    if (lane == 0) { red[0][wave] = res; red[1][wave] = tot; red[2][wave] = dacc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0, t = 0.0, d = 0.0;
+        for (int w = 0; w < WAVES_PER_BLOCK; ++w) { r += red[0][w]; t += red[1][w]; d += red[2][w]; }
+        a.res_part[blockIdx.x] = r;
+        a.sum_part[blockIdx.x] = t;
+        if (dang) a.y[my_base + a.geo.rows_cap + bd.dslot] = d;
+    }
+}
+
+struct StepArgsFr {
+    const BlockDesc* blocks;
+    const SliceDesc* slices;
+    const uint32_t* col;
+    const uint4* wlo;
+    const uint4* whi;
+    const uint4* x;
+    uint4* y;
+    uint4* sum_part;       // [n_blocks][2]
+    uint32_t* chg_part;    // [n_blocks]
+    Geometry geo;
+    U256 inv_nm1_w;        // inv(n_valid-1) * 2^288 mod r
+};
+
+ET_DEV U256 fr_wave_sum(U256 v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        U256 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.v[i] = __shfl_xor(v.v[i], off, 64);
+        v = fr_add(v, o);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(BLOCK_THREADS) void k_step_fr(StepArgsFr a) {
+    __shared__ uint32_t sh_d[9];                       // integer sum of the partial sums, plus r (< 2^288)
+    __shared__ uint32_t sh_pd[17];                     // inv_nm1_w * that sum, unreduced
+    __shared__ uint32_t sh_tot[WAVES_PER_BLOCK][8];
+    __shared__ uint32_t sh_dac[WAVES_PER_BLOCK][8];
+    __shared__ uint32_t sh_chg[WAVES_PER_BLOCK];
+    const BlockDesc bd = a.blocks[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t stride = a.geo.seg_stride();
+    const size_t my_base = (size_t)a.geo.seg * stride;
+    const bool dang = (bd.flags & BLOCK_DANGLING) != 0;
+
+    if (wave == 0) {
+        Acc d = acc_zero();
+        const uint32_t total = a.geo.n_seg * a.geo.nd_cap;
+        for (uint32_t t = lane; t < total; t += 64) {
+            uint32_t sg = t / a.geo.nd_cap, k = t - sg * a.geo.nd_cap;
+            U256 p = u256_load(a.x + 2 * ((size_t)sg * stride + a.geo.rows_cap + k));
+            acc_add_u256(d, p);
+        }
+        acc_wave_sum(d);  // < 2^(254+log2(total)) : limbs 0..8
+        Acc pd = acc_zero();
+        U256 dlo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dlo.v[i] = d.v[i];
+        acc_mac(pd, a.inv_nm1_w, dlo);
+        // + inv_nm1_w * d.v[8] * 2^256
+        {
+            uint64_t c = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint64_t t = (uint64_t)a.inv_nm1_w.v[j] * d.v[8] + pd.v[8 + j] + c;
+                pd.v[8 + j] = (uint32_t)t;
+                c = t >> 32;
+            }
+            pd.v[16] += (uint32_t)c;
+        }
+        if (lane == 0) {
+            // D + r: the partial sums are reduced mod r, so D may be smaller than one of its own
+            // summands as an integer; (D + r - old) is the non-negative representative a dangling
+            // row needs
+            uint64_t c = 0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                uint64_t t = (uint64_t)d.v[i] + (i < 8 ? FR_P[i] : 0u) + c;
+                sh_d[i] = (uint32_t)t;
+                c = t >> 32;
+            }
+#pragma unroll
+            for (int i = 0; i < 17; ++i) sh_pd[i] = pd.v[i];
+        }
+    }
+    __syncthreads();
+    Acc PD;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) PD.v[i] = sh_pd[i];
+
+    U256 tot = u256_zero(), dacc = u256_zero();
+    uint32_t changed = 0;
+    for (uint32_t s = bd.slice_begin + wave; s < bd.slice_end; s += WAVES_PER_BLOCK) {
+        const SliceDesc sd = a.slices[s];
+        const uint32_t* __restrict__ cp = a.col + (size_t)sd.off * 64 + lane;
+        const uint4* __restrict__ lop = a.wlo + (size_t)sd.off * 64 + lane;
+        const uint4* __restrict__ hip_ = a.whi + (size_t)sd.off * 64 + lane;
+        Acc acc = acc_zero();
+#pragma unroll 2
+        for (uint32_t k = 0; k < sd.len; ++k) {
+            uint32_t c = cp[(size_t)k * 64];
+            U256 w = u256_from_planes(lop[(size_t)k * 64], hip_[(size_t)k * 64]);
+            U256 xv = u256_load(a.x + 2 * (size_t)c);
+            acc_mac(acc, w, xv);
+        }
+        const bool reduce = (sd.nrows & SLICE_REDUCE) != 0;
+        if (reduce) acc_wave_sum(acc);
+        const uint32_t row = reduce ? sd.row0 : sd.row0 + lane;
+        const bool live = reduce ? lane == 0 : (uint32_t)lane < (sd.nrows & 0xFFu);
+        if (live) {
+            U256 old = u256_load(a.x + 2 * (my_base + row));
+            if (dang) {
+                // (D + r - old) as a 9-limb integer: old < r, so no borrow out
+                uint32_t diff[9];
+                uint64_t br = 0;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    uint64_t t = (uint64_t)sh_d[i] - (i < 8 ? old.v[i] : 0u) - br;
+                    diff[i] = (uint32_t)t;
+                    br = (t >> 32) & 1;
+                }
+                U256 dlo;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dlo.v[i] = diff[i];
+                acc_mac(acc, a.inv_nm1_w, dlo);
+                uint64_t c = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    uint64_t t = (uint64_t)a.inv_nm1_w.v[j] * diff[8] + acc.v[8 + j] + c;
+                    acc.v[8 + j] = (uint32_t)t;
+                    c = t >> 32;
+                }
+                acc.v[16] += (uint32_t)c;
+            } else {
+                acc_add(acc, PD);
+            }
+            U256 v = acc_redc288(acc);
+            u256_store(a.y + 2 * (my_base + row), v);
+            changed += u256_eq(v, old) ? 0u : 1u;
+            tot = fr_add(tot, v);
+            if (dang) dacc = fr_add(dacc, v);
+        }
+    }
+    tot = fr_wave_sum(tot);
+    if (dang) dacc = fr_wave_sum(dacc);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) changed += __shfl_xor(changed, off, 64);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sh_tot[wave][i] = tot.v[i]; sh_dac[wave][i] = dacc.v[i]; }
+        sh_chg[wave] = changed;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        U256 t = u256_zero(), d = u256_zero();
+        uint32_t c = 0;
+        for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+            U256 tw, dw;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { tw.v[i] = sh_tot[w][i]; dw.v[i] = sh_dac[w][i]; }
+            t = fr_add(t, tw);
+            d = fr_add(d, dw);
+            c += sh_chg[w];
+        }
+        u256_store(a.sum_part + 2 * (size_t)blockIdx.x, t);
+        a.chg_part[blockIdx.x] = c;
+        if (dang) u256_store(a.y + 2 * (my_base + a.geo.rows_cap + bd.dslot), d);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels: statistics, un-permutation, self-test
+// ---------------------------------------------------------------------------------------------
+__global__ void k_stats_f64(const double* __restrict__ res_part, const double* __restrict__ sum_part,
+                            uint32_t n_blocks, double* __restrict__ out2) {
+    // one wavefront, fixed order
+    double r = 0.0, t = 0.0;
+    for (uint32_t i = threadIdx.x; i < n_blocks; i += 64) { r += res_part[i]; t += sum_part[i]; }
+    r = wave_sum_f64(r);
+    t = wave_sum_f64(t);
+    if (threadIdx.x == 0) { out2[0] = r; out2[1] = t; }
+}
+__global__ void k_stats_fr(const uint4* __restrict__ sum_part, const uint32_t* __restrict__ chg_part,
+                           uint32_t n_blocks, uint4* __restrict__ out_sum, unsigned long long* __restrict__ out_chg) {
+    U256 t = u256_zero();
+    unsigned long long c = 0;
+    for (uint32_t i = threadIdx.x; i < n_blocks; i += 64) {
+        t = fr_add(t, u256_load(sum_part + 2 * (size_t)i));
+        c += chg_part[i];
+    }
+    t = fr_wave_sum(t);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+    if (threadIdx.x == 0) { u256_store(out_sum, t); *out_chg = c; }
+}
+__global__ void k_unpermute_f64(const uint32_t* __restrict__ pos, const double* __restrict__ x, double* __restrict__ out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t p = pos[i];
+    out[i] = p == 0xFFFFFFFFu ? 0.0 : x[p];
+}
+__global__ void k_unpermute_fr(const uint32_t* __restrict__ pos, const uint4* __restrict__ x, uint4* __restrict__ out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t p = pos[i];
+    U256 v = p == 0xFFFFFFFFu ? u256_zero() : u256_load(x + 2 * (size_t)p);
+    u256_store(out + 2 * (size_t)i, v);
+}
+// a * b mod r through the same multiply-accumulate and reduction the step kernel uses:
+// (a * 2^576 * 2^-288) * b * 2^-288.  `c576` = 2^576 mod r.
+__global__ void k_fr_mul_test(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ out, U256 c576, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    U256 av = u256_load(a + 2 * (size_t)i), bv = u256_load(b + 2 * (size_t)i);
+    Acc t = acc_zero();
+    acc_mac(t, av, c576);
+    U256 aw = acc_redc288(t);  // a * 2^288
+    Acc u = acc_zero();
+    acc_mac(u, aw, bv);
+    // exercise the wavefront sum as well: every lane adds its product, lane totals are compared
+    // on the host against per-element results, so only add zero from the other lanes
+    U256 r = acc_redc288(u);
+    u256_store(out + 2 * (size_t)i, r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// DeviceGraph
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int dev_alloc(T** p, size_t count, uint64_t& total) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIP_TRY(hipMalloc((void**)p, count * sizeof(T)));
+    total += count * sizeof(T);
+    return ET_OK;
+}
+template <typename T>
+static int dev_upload(T** p, const std::vector<T>& v, uint64_t& total) {
+    int rc = dev_alloc(p, v.size(), total);
+    if (rc) return rc;
+    if (!v.empty()) HIP_TRY(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return ET_OK;
+}
+
+DeviceGraph::~DeviceGraph() {
+    if (device >= 0) (void)hipSetDevice(device);
+    void* ptrs[] = {d_blocks, d_slices, d_col, d_w64, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
+                    d_chg_part, d_stat_out, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (ev0) (void)hipEventDestroy((hipEvent_t)ev0);
+    if (ev1) (void)hipEventDestroy((hipEvent_t)ev1);
+}
+
+static U256 to_u256(const FrRaw& r) {
+    U256 u;
+    for (int i = 0; i < 4; ++i) { u.v[2 * i] = (uint32_t)r.l[i]; u.v[2 * i + 1] = (uint32_t)(r.l[i] >> 32); }
+    return u;
+}
+
+int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGraph** out) {
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { set_error("no HIP device"); return ET_E_NO_DEVICE; }
+    if (device_ < 0) HIP_TRY(hipGetDevice(&device_));
+    HIP_TRY(hipSetDevice(device_));
+    std::unique_ptr<DeviceGraph> g(new DeviceGraph());
+    g->device = device_;
+    g->variants = variants_ ? variants_ : (ET_VARIANT_FR | ET_VARIANT_F64);
+    g->n = h.n; g->n_valid = h.n_valid; g->nnz = h.nnz; g->nnz_local = h.nnz_local;
+    g->geo = h.geo; g->n_steps = h.n_steps; g->n_slices = (uint32_t)h.slices.size();
+    g->n_blocks = (uint32_t)h.blocks.size(); g->n_dangling_local = h.n_dangling_local;
+    g->pos_of_ext = h.pos_of_ext;
+    g->inv_nm1_w = h.inv_nm1_w;
+    g->inv_nm1 = 1.0 / (double)(h.n_valid - 1);
+    uint64_t& tot = g->device_bytes;
+    int rc;
+    if ((rc = dev_upload(&g->d_blocks, h.blocks, tot))) return rc;
+    if ((rc = dev_upload(&g->d_slices, h.slices, tot))) return rc;
+    if ((rc = dev_upload(&g->d_col, h.col, tot))) return rc;
+    if ((rc = dev_upload(&g->d_pos, h.pos_of_ext, tot))) return rc;
+    const size_t slots = (size_t)h.n_steps * 64;
+    const size_t vec_len = (size_t)h.geo.n_seg * h.geo.seg_stride();
+    g->vec_len = vec_len;
+    // raw opinions and source factors are only needed until the weights are computed
+    uint64_t tmp_bytes = 0;
+    uint32_t* d_val32 = nullptr; uint4* d_valfr = nullptr; uint4* d_scale_fr = nullptr; double* d_scale64 = nullptr;
+    auto free_tmp = [&]() { if (d_val32) (void)hipFree(d_val32); if (d_valfr) (void)hipFree(d_valfr); if (d_scale_fr) (void)hipFree(d_scale_fr); if (d_scale64) (void)hipFree(d_scale64); };
+    if (h.values_are_u32) rc = dev_upload(&d_val32, h.val_u32, tmp_bytes);
+    else {
+        rc = dev_alloc(&d_valfr, slots * 2, tmp_bytes);
+        if (!rc && slots) HIP_TRY(hipMemcpy(d_valfr, h.val_fr.data(), slots * 32, hipMemcpyHostToDevice));
+    }
+    if (rc) { free_tmp(); return rc; }
+    const unsigned nb = (unsigned)((slots + 255) / 256);
+    if (g->variants & ET_VARIANT_F64) {
+        if ((rc = dev_upload(&d_scale64, h.scale_f64, tmp_bytes)) || (rc = dev_alloc(&g->d_w64, slots, tot))) { free_tmp(); return rc; }
+        if (slots) {
+            if (h.values_are_u32) hipLaunchKernelGGL(k_normalise_f64_u32, dim3(nb), dim3(256), 0, 0, g->d_col, d_val32, d_scale64, g->d_w64, slots);
+            else hipLaunchKernelGGL(k_normalise_f64_fr, dim3(nb), dim3(256), 0, 0, g->d_col, d_valfr, d_scale64, g->d_w64, slots);
+        }
+        for (int i = 0; i < 2; ++i) {
+            if ((rc = dev_alloc(&g->vx[i], vec_len, tot))) { free_tmp(); return rc; }
+            HIP_TRY(hipMemset(g->vx[i], 0, vec_len * sizeof(double)));
+        }
+        if ((rc = dev_alloc(&g->out_f64, h.n, tot)) || (rc = dev_alloc(&g->d_res_part, (size_t)STATS_RING * g->n_blocks, tot)) ||
+            (rc = dev_alloc(&g->d_sum_part, (size_t)STATS_RING * g->n_blocks, tot))) { free_tmp(); return rc; }
+    }
+    if (g->variants & ET_VARIANT_FR) {
+        rc = dev_alloc(&d_scale_fr, vec_len * 2, tmp_bytes);
+        if (!rc) HIP_TRY(hipMemcpy(d_scale_fr, h.scale_fr.data(), vec_len * 32, hipMemcpyHostToDevice));
+        if (rc || (rc = dev_alloc(&g->d_wlo, slots, tot)) || (rc = dev_alloc(&g->d_whi, slots, tot))) { free_tmp(); return rc; }
+        if (slots) {
+            if (h.values_are_u32) hipLaunchKernelGGL(k_normalise_fr_u32, dim3(nb), dim3(256), 0, 0, g->d_col, d_val32, d_scale_fr, g->d_wlo, g->d_whi, slots);
+            else hipLaunchKernelGGL(k_normalise_fr_fr, dim3(nb), dim3(256), 0, 0, g->d_col, d_valfr, d_scale_fr, g->d_wlo, g->d_whi, slots);
+        }
+        for (int i = 0; i < 2; ++i) {
+            if ((rc = dev_alloc(&g->fx[i], vec_len * 2, tot))) { free_tmp(); return rc; }
+            HIP_TRY(hipMemset(g->fx[i], 0, vec_len * 32));
+        }
+        if ((rc = dev_alloc(&g->out_fr, (size_t)h.n * 2, tot)) || (rc = dev_alloc(&g->d_frsum_part, (size_t)STATS_RING * g->n_blocks * 2, tot)) ||
+            (rc = dev_alloc(&g->d_chg_part, (size_t)STATS_RING * g->n_blocks, tot))) { free_tmp(); return rc; }
+    }
+    if ((rc = dev_alloc(&g->d_stat_out, 64, tot))) { free_tmp(); return rc; }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    free_tmp();
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    g->ev0 = e0; g->ev1 = e1;
+    *out = g.release();
+    return ET_OK;
+}
+
+int DeviceGraph::init_f64(double initial, double* x, hipStream_t st) {
+    if (!(variants & ET_VARIANT_F64)) { set_error("graph was built without the f64 variant"); return ET_E_UNSUPPORTED; }
+    uint32_t stride = geo.seg_stride();
+    double d0 = (double)n_dangling_local * initial;
+    hipLaunchKernelGGL(k_init_f64, dim3((stride + 255) / 256), dim3(256), 0, st, geo, initial, d0, x);
+    HIP_TRY(hipGetLastError());
+    return ET_OK;
+}
+int DeviceGraph::init_fr(uint64_t lo, uint64_t hi, uint4* x, hipStream_t st) {
+    if (!(variants & ET_VARIANT_FR)) { set_error("graph was built without the Fr variant"); return ET_E_UNSUPPORTED; }
+    uint32_t stride = geo.seg_stride();
+    Fr init = Fr::from_u128(lo, hi);
+    Fr d0 = init * Fr::from_u64(n_dangling_local);
+    hipLaunchKernelGGL(k_init_fr, dim3((stride + 255) / 256), dim3(256), 0, st, geo, to_u256(init.to_raw()), to_u256(d0.to_raw()), x);
+    HIP_TRY(hipGetLastError());
+    return ET_OK;
+}
+int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, hipStream_t st) {
+    if (!(variants & ET_VARIANT_F64)) { set_error("graph was built without the f64 variant"); return ET_E_UNSUPPORTED; }
+    if (x == y) { set_error("step needs distinct input and output vectors"); return ET_E_INVALID_ARG; }
+    StepArgsF64 a;
+    a.blocks = d_blocks; a.slices = d_slices; a.col = d_col; a.w = d_w64; a.x = x; a.y = y; a.pretrust = pretrust;
+    size_t ring = (size_t)(iteration % STATS_RING) * n_blocks;
+    a.res_part = d_res_part + ring; a.sum_part = d_sum_part + ring;
+    a.geo = geo; a.inv_nm1 = inv_nm1; a.alpha = alpha;
+    if (n_blocks == 0) return ET_OK;
+    if (alpha != 0.0) {
+        if (!pretrust) { set_error("alpha != 0 needs a pre-trust vector"); return ET_E_INVALID_ARG; }
+        hipLaunchKernelGGL(k_step_f64<true>, dim3(n_blocks), dim3(BLOCK_THREADS), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(k_step_f64<false>, dim3(n_blocks), dim3(BLOCK_THREADS), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return ET_OK;
+}
+int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, hipStream_t st) {
+    if (!(variants & ET_VARIANT_FR)) { set_error("graph was built without the Fr variant"); return ET_E_UNSUPPORTED; }
+    if (x == y) { set_error("step needs distinct input and output vectors"); return ET_E_INVALID_ARG; }
+    StepArgsFr a;
+    a.blocks = d_blocks; a.slices = d_slices; a.col = d_col; a.wlo = d_wlo; a.whi = d_whi; a.x = x; a.y = y;
+    size_t ring = (size_t)(iteration % STATS_RING) * n_blocks;
+    a.sum_part = d_frsum_part + 2 * ring; a.chg_part = d_chg_part + ring;
+    a.geo = geo; a.inv_nm1_w = to_u256(inv_nm1_w);
+    if (n_blocks == 0) return ET_OK;
+    hipLaunchKernelGGL(k_step_fr, dim3(n_blocks), dim3(BLOCK_THREADS), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return ET_OK;
+}
+int DeviceGraph::unpermute_f64(const double* x, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_unpermute_f64, dim3((n + 255) / 256), dim3(256), 0, st, d_pos, x, out, n);
+    HIP_TRY(hipGetLastError());
+    return ET_OK;
+}
+int DeviceGraph::unpermute_fr(const uint4* x, uint4* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_unpermute_fr, dim3((n + 255) / 256), dim3(256), 0, st, d_pos, x, out, n);
+    HIP_TRY(hipGetLastError());
+    return ET_OK;
+}
+int DeviceGraph::stats_f64(uint32_t iteration, hipStream_t st, et_iter_stats* out) {
+    if (!(variants & ET_VARIANT_F64)) return ET_E_UNSUPPORTED;
+    size_t ring = (size_t)(iteration % STATS_RING) * n_blocks;
+    double* o = (double*)d_stat_out;
+    hipLaunchKernelGGL(k_stats_f64, dim3(1), dim3(64), 0, st, d_res_part + ring, d_sum_part + ring, n_blocks, o);
+    HIP_TRY(hipGetLastError());
+    double h[2];
+    HIP_TRY(hipMemcpyAsync(h, o, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::memset(out, 0, sizeof(*out));
+    out->residual_l1 = h[0];
+    out->sum_f64 = h[1];
+    return ET_OK;
+}
+int DeviceGraph::stats_fr(uint32_t iteration, hipStream_t st, et_iter_stats* out) {
+    if (!(variants & ET_VARIANT_FR)) return ET_E_UNSUPPORTED;
+    size_t ring = (size_t)(iteration % STATS_RING) * n_blocks;
+    uint4* o = (uint4*)d_stat_out;
+    unsigned long long* oc = (unsigned long long*)(o + 2);
+    hipLaunchKernelGGL(k_stats_fr, dim3(1), dim3(64), 0, st, d_frsum_part + 2 * ring, d_chg_part + ring, n_blocks, o, oc);
+    HIP_TRY(hipGetLastError());
+    uint8_t h[40];
+    HIP_TRY(hipMemcpyAsync(h, o, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::memset(out, 0, sizeof(*out));
+    std::memcpy(out->sum.b, h, 32);
+    std::memcpy(&out->changed, h + 32, 8);
+    return ET_OK;
+}
+
+int DeviceGraph::run_f64(uint32_t iters, double initial, double alpha, hipStream_t st, float* step_ms) {
+    if (geo.n_seg != 1) { set_error("run needs the whole graph on one GPU"); return ET_E_UNSUPPORTED; }
+    int rc = init_f64(initial, vx[0], st);
+    if (rc) return rc;
+    const double* pre = nullptr;
+    if (alpha != 0.0) {
+        // default pre-trust: the initial vector
+        if (!d_pretrust) {
+            uint64_t dummy = 0;
+            if ((rc = dev_alloc(&d_pretrust, vec_len, dummy))) return rc;
+            device_bytes += dummy;
+        }
+        HIP_TRY(hipMemcpyAsync(d_pretrust, vx[0], vec_len * sizeof(double), hipMemcpyDeviceToDevice, st));
+        pre = d_pretrust;
+    }
+    if (step_ms) HIP_TRY(hipEventRecord((hipEvent_t)ev0, st));
+    for (uint32_t it = 0; it < iters; ++it)
+        if ((rc = step_f64(vx[it & 1], vx[(it + 1) & 1], it, alpha, pre, st))) return rc;
+    if (step_ms) HIP_TRY(hipEventRecord((hipEvent_t)ev1, st));
+    if ((rc = unpermute_f64(vx[iters & 1], out_f64, st))) return rc;
+    last_iters = iters;
+    if (step_ms) {
+        HIP_TRY(hipEventSynchronize((hipEvent_t)ev1));
+        HIP_TRY(hipEventElapsedTime(step_ms, (hipEvent_t)ev0, (hipEvent_t)ev1));
+    }
+    return ET_OK;
+}
+int DeviceGraph::run_fr(uint32_t iters, uint64_t lo, uint64_t hi, hipStream_t st, float* step_ms) {
+    if (geo.n_seg != 1) { set_error("run needs the whole graph on one GPU"); return ET_E_UNSUPPORTED; }
+    int rc = init_fr(lo, hi, fx[0], st);
+    if (rc) return rc;
+    if (step_ms) HIP_TRY(hipEventRecord((hipEvent_t)ev0, st));
+    for (uint32_t it = 0; it < iters; ++it)
+        if ((rc = step_fr(fx[it & 1], fx[(it + 1) & 1], it, st))) return rc;
+    if (step_ms) HIP_TRY(hipEventRecord((hipEvent_t)ev1, st));
+    if ((rc = unpermute_fr(fx[iters & 1], out_fr, st))) return rc;
+    last_iters = iters;
+    if (step_ms) {
+        HIP_TRY(hipEventSynchronize((hipEvent_t)ev1));
+        HIP_TRY(hipEventElapsedTime(step_ms, (hipEvent_t)ev0, (hipEvent_t)ev1));
+    }
+    return ET_OK;
+}
+
+int dev_fr_mul(uint32_t count, const et_fr* a, const et_fr* b, et_fr* out) {
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { set_error("no HIP device"); return ET_E_NO_DEVICE; }
+    uint4 *da = nullptr, *db = nullptr, *dc = nullptr;
+    size_t bytes = (size_t)count * 32;
+    HIP_TRY(hipMalloc((void**)&da, bytes ? bytes : 32));
+    HIP_TRY(hipMalloc((void**)&db, bytes ? bytes : 32));
+    HIP_TRY(hipMalloc((void**)&dc, bytes ? bytes : 32));
+    HIP_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
+    U256 c576 = to_u256(Fr::one().pow2k(576).to_raw());
+    if (count) hipLaunchKernelGGL(k_fr_mul_test, dim3((count + 255) / 256), dim3(256), 0, 0, da, db, dc, c576, count);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dc, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc);
+    return ET_OK;
+}
+
+}  // namespace et

@@ -1,0 +1,69 @@
+// Device-resident prepared graph and the launches that iterate it (implementation: engine.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/eigentrust_hip.h"
+#include "builder.hpp"
+
+namespace et {
+
+void set_error(const std::string& s);
+const char* last_error();
+
+struct DeviceGraph {
+    int device = -1;
+    int variants = 0;
+    uint32_t n = 0, n_valid = 0;
+    uint64_t nnz = 0, nnz_local = 0, n_steps = 0;
+    uint32_t n_slices = 0, n_blocks = 0, n_dangling_local = 0;
+    Geometry geo{};
+    size_t vec_len = 0;
+    uint64_t device_bytes = 0;
+    std::vector<uint32_t> pos_of_ext;
+    FrRaw inv_nm1_w{};
+    double inv_nm1 = 0.0;
+    uint32_t last_iters = 0;
+
+    BlockDesc* d_blocks = nullptr;
+    SliceDesc* d_slices = nullptr;
+    uint32_t* d_col = nullptr;
+    double* d_w64 = nullptr;
+    uint4* d_wlo = nullptr;
+    uint4* d_whi = nullptr;
+    uint32_t* d_pos = nullptr;
+    double* d_res_part = nullptr;
+    double* d_sum_part = nullptr;
+    uint4* d_frsum_part = nullptr;
+    uint32_t* d_chg_part = nullptr;
+    uint4* d_stat_out = nullptr;
+    double* vx[2] = {nullptr, nullptr};
+    uint4* fx[2] = {nullptr, nullptr};
+    double* out_f64 = nullptr;
+    uint4* out_fr = nullptr;
+    double* d_pretrust = nullptr;
+    void* ev0 = nullptr;
+    void* ev1 = nullptr;
+
+    ~DeviceGraph();
+    static int create(const HostGraph& h, int variants, int device, DeviceGraph** out);
+
+    int init_f64(double initial, double* x, hipStream_t st);
+    int init_fr(uint64_t lo, uint64_t hi, uint4* x, hipStream_t st);
+    int step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, hipStream_t st);
+    int step_fr(const uint4* x, uint4* y, uint32_t iteration, hipStream_t st);
+    int unpermute_f64(const double* x, double* out, hipStream_t st);
+    int unpermute_fr(const uint4* x, uint4* out, hipStream_t st);
+    int stats_f64(uint32_t iteration, hipStream_t st, et_iter_stats* out);
+    int stats_fr(uint32_t iteration, hipStream_t st, et_iter_stats* out);
+    int run_f64(uint32_t iters, double initial, double alpha, hipStream_t st, float* step_ms);
+    int run_fr(uint32_t iters, uint64_t lo, uint64_t hi, hipStream_t st, float* step_ms);
+};
+
+int dev_fr_mul(uint32_t count, const et_fr* a, const et_fr* b, et_fr* out);
+
+}  // namespace et

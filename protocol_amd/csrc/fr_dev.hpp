@@ -1,0 +1,235 @@
+// Device-side BN254 scalar field arithmetic for the exact (Fr) kernels: 8 x 32-bit limbs.
+//
+// The reference multiplies and adds `bn256::Fr` values in its hot loop
+// (dynamic_sets/native.rs:323-324).  Here a row's dot product is accumulated UNREDUCED: each
+// 256 x 256-bit product is added as a plain integer to a 17-limb (544-bit) accumulator, and one
+// Montgomery reduction per row brings the sum back below r.  Edge weights are stored pre-multiplied
+// by 2^288 mod r, so that reduction (nine 32-bit rounds, i.e. division by 2^288) returns exactly
+// sum_j c_ji * s[j] mod r in canonical form.  A 544-bit accumulator holds 2^34 products of
+// canonical operands, more than any row can have.  Integer addition is associative, so the result
+// does not depend on how a row's products are spread over lanes: it is bit-exact by construction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace et {
+
+#define ET_DEV __device__ __forceinline__
+
+// r, little-endian 32-bit limbs
+__device__ static constexpr uint32_t FR_P[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                                0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+static constexpr uint32_t FR_N0_32 = 0xefffffffu;  // -r^-1 mod 2^32
+
+struct U256 {
+    uint32_t v[8];
+};
+
+ET_DEV U256 u256_load(const uint4* p) {  // 32-byte aligned field element
+    uint4 lo = p[0], hi = p[1];
+    U256 r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+ET_DEV void u256_store(uint4* p, const U256& a) {
+    p[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    p[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+ET_DEV U256 u256_from_planes(uint4 lo, uint4 hi) {
+    U256 r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+ET_DEV U256 u256_zero() {
+    U256 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = 0;
+    return r;
+}
+ET_DEV bool u256_eq(const U256& a, const U256& b) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d |= a.v[i] ^ b.v[i];
+    return d == 0;
+}
+ET_DEV bool u256_geq_p(const U256& a) {
+    // a >= r  <=>  a - r does not borrow
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t d = (uint64_t)a.v[i] - FR_P[i] - br;
+        br = (d >> 32) & 1;
+    }
+    return br == 0;
+}
+ET_DEV U256 u256_sub_p_if_geq(const U256& a) {
+    U256 d;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t t = (uint64_t)a.v[i] - FR_P[i] - br;
+        d.v[i] = (uint32_t)t;
+        br = (t >> 32) & 1;
+    }
+    U256 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = br ? a.v[i] : d.v[i];
+    return r;
+}
+// (a + b) mod r for canonical a, b   (a + b < 2r < 2^255: no carry out of 256 bits)
+ET_DEV U256 fr_add(const U256& a, const U256& b) {
+    U256 s;
+    uint64_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t t = (uint64_t)a.v[i] + b.v[i] + cy;
+        s.v[i] = (uint32_t)t;
+        cy = t >> 32;
+    }
+    return u256_sub_p_if_geq(s);
+}
+// (a - b) mod r for canonical a, b
+ET_DEV U256 fr_sub(const U256& a, const U256& b) {
+    U256 d;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t t = (uint64_t)a.v[i] - b.v[i] - br;
+        d.v[i] = (uint32_t)t;
+        br = (t >> 32) & 1;
+    }
+    uint64_t cy = 0;
+    U256 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t t = (uint64_t)d.v[i] + (br ? FR_P[i] : 0u) + cy;
+        r.v[i] = (uint32_t)t;
+        cy = t >> 32;
+    }
+    return r;
+}
+
+// 544-bit unreduced accumulator
+struct Acc {
+    uint32_t v[17];
+};
+ET_DEV Acc acc_zero() {
+    Acc a;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) a.v[i] = 0;
+    return a;
+}
+ET_DEV void acc_add(Acc& a, const Acc& b) {
+    uint64_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {
+        uint64_t t = (uint64_t)a.v[i] + b.v[i] + cy;
+        a.v[i] = (uint32_t)t;
+        cy = t >> 32;
+    }
+}
+ET_DEV void acc_add_u256(Acc& a, const U256& b) {
+    uint64_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t t = (uint64_t)a.v[i] + b.v[i] + cy;
+        a.v[i] = (uint32_t)t;
+        cy = t >> 32;
+    }
+#pragma unroll
+    for (int i = 8; i < 17; ++i) {
+        uint64_t t = (uint64_t)a.v[i] + cy;
+        a.v[i] = (uint32_t)t;
+        cy = t >> 32;
+    }
+}
+
+// acc += a * b  (schoolbook 8 x 8 into a fresh 16-limb product, then one 17-limb add)
+ET_DEV void acc_mac(Acc& acc, const U256& a, const U256& b) {
+    uint32_t p[16];
+    {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t t = (uint64_t)a.v[j] * b.v[0] + c;
+            p[j] = (uint32_t)t;
+            c = t >> 32;
+        }
+        p[8] = (uint32_t)c;
+    }
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t t = (uint64_t)a.v[j] * b.v[i] + p[i + j] + c;
+            p[i + j] = (uint32_t)t;
+            c = t >> 32;
+        }
+        p[i + 8] = (uint32_t)c;
+    }
+    uint64_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        uint64_t t = (uint64_t)acc.v[i] + p[i] + cy;
+        acc.v[i] = (uint32_t)t;
+        cy = t >> 32;
+    }
+    acc.v[16] += (uint32_t)cy;
+}
+// acc += a * v  (32-bit opinion times field element)
+ET_DEV void acc_mac_u32(Acc& acc, const U256& a, uint32_t v) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uint64_t t = (uint64_t)a.v[j] * v + acc.v[j] + c;
+        acc.v[j] = (uint32_t)t;
+        c = t >> 32;
+    }
+#pragma unroll
+    for (int j = 8; j < 17; ++j) {
+        uint64_t t = (uint64_t)acc.v[j] + c;
+        acc.v[j] = (uint32_t)t;
+        c = t >> 32;
+    }
+}
+
+// acc * 2^-288 mod r, canonical.  Requires acc < r * 2^288 (any sum of < 2^34 canonical products).
+ET_DEV U256 acc_redc288(Acc a) {
+    uint32_t carry2 = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        uint32_t m = a.v[i] * FR_N0_32;
+        uint64_t t = (uint64_t)m * FR_P[0] + a.v[i];
+        uint64_t c = t >> 32;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            t = (uint64_t)m * FR_P[j] + a.v[i + j] + c;
+            a.v[i + j] = (uint32_t)t;
+            c = t >> 32;
+        }
+        // limb i+8 exists for every i <= 8
+        t = (uint64_t)a.v[i + 8] + c + carry2;
+        a.v[i + 8] = (uint32_t)t;
+        carry2 = (uint32_t)(t >> 32);
+    }
+    U256 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = a.v[9 + i];
+    return u256_sub_p_if_geq(r);
+}
+
+// Wavefront-wide integer sum of accumulators; every lane receives the total.
+ET_DEV void acc_wave_sum(Acc& a) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Acc o;
+#pragma unroll
+        for (int i = 0; i < 17; ++i) o.v[i] = __shfl_xor(a.v[i], off, 64);
+        acc_add(a, o);
+    }
+}
+
+}  // namespace et

@@ -1,0 +1,142 @@
+"""Python handle on the C-ABI graph engine (et_graph_* in include/eigentrust_hip.h)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, lib
+
+R_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def fr_bytes_from_ints(vals):
+    """list of python ints -> uint8 array [len, 32], canonical little-endian."""
+    out = np.zeros((len(vals), 32), dtype=np.uint8)
+    for i, v in enumerate(vals):
+        out[i] = np.frombuffer(int(v).to_bytes(32, "little"), dtype=np.uint8)
+    return out
+
+
+def fr_ints_from_bytes(arr):
+    b = np.ascontiguousarray(arr, dtype=np.uint8).tobytes()
+    return [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
+
+
+def synth_graph(kind, n, target_edges, seed=42, value_max=255):
+    """Deterministic synthetic attestation list (et_synth_graph): returns from, to, value."""
+    ne = C.c_uint64(0)
+    check(lib().et_synth_graph(kind, n, target_edges, seed, value_max, C.byref(ne), None, None, None))
+    frm = np.empty(ne.value, dtype=np.uint32)
+    to = np.empty(ne.value, dtype=np.uint32)
+    val = np.empty(ne.value, dtype=np.uint32)
+    check(lib().et_synth_graph(kind, n, target_edges, seed, value_max, C.byref(ne), _ptr(frm), _ptr(to), _ptr(val)))
+    return frm, to, val
+
+
+class Graph:
+    """A filtered, normalised attestation graph resident on one GPU."""
+
+    def __init__(self, n, frm, to, value_u32=None, value_fr=None, member=None, n_seg=1, seg=0,
+                 variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64, device=-1, long_row=0,
+                 target_blocks=0):
+        frm = np.ascontiguousarray(frm, dtype=np.uint32)
+        to = np.ascontiguousarray(to, dtype=np.uint32)
+        if len(frm) != len(to):
+            raise ValueError("from/to length mismatch")
+        if value_u32 is not None:
+            value_u32 = np.ascontiguousarray(value_u32, dtype=np.uint32)
+        if value_fr is not None:
+            value_fr = np.ascontiguousarray(value_fr, dtype=np.uint8)
+        if member is not None:
+            member = np.ascontiguousarray(member, dtype=np.uint8)
+            if len(member) != n:
+                raise ValueError("member flags must have n entries")
+        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_blocks, variants, device)
+        h = C.c_void_p()
+        check(lib().et_graph_build(n, _ptr(member), len(frm), _ptr(frm), _ptr(to), _ptr(value_u32),
+                                   _ptr(value_fr), C.byref(opts), C.byref(h)))
+        self._h = h
+        self.n = n
+        info = _ffi.EtGraphInfo()
+        check(lib().et_graph_info_get(self._h, C.byref(info)))
+        self.info = info
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().et_graph_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # whole converge, host in / host out ------------------------------------------------------
+    def converge_fr(self, num_iterations=20, initial=1000):
+        out = np.zeros((self.n, 32), dtype=np.uint8)
+        check(lib().et_graph_converge_fr(self._h, num_iterations, initial & (2**64 - 1), initial >> 64, _ptr(out)))
+        return out
+
+    def converge_f64(self, num_iterations=20, initial=1000.0, alpha=0.0, pretrust=None):
+        out = np.zeros(self.n, dtype=np.float64)
+        res = C.c_double(0)
+        if pretrust is not None:
+            pretrust = np.ascontiguousarray(pretrust, dtype=np.float64)
+        check(lib().et_graph_converge_f64(self._h, num_iterations, initial, alpha, _ptr(pretrust), _ptr(out), C.byref(res)))
+        return out, res.value
+
+    # device-resident runs ------------------------------------------------------------------------
+    def run_fr(self, num_iterations=20, initial=1000, stream=None, timed=False):
+        ms = C.c_float(0)
+        check(lib().et_graph_run_fr(self._h, num_iterations, initial & (2**64 - 1), initial >> 64, stream,
+                                    C.byref(ms) if timed else None))
+        return ms.value
+
+    def run_f64(self, num_iterations=20, initial=1000.0, alpha=0.0, stream=None, timed=False):
+        ms = C.c_float(0)
+        check(lib().et_graph_run_f64(self._h, num_iterations, initial, alpha, stream, C.byref(ms) if timed else None))
+        return ms.value
+
+    def result_fr(self, stream=None):
+        out = np.zeros((self.n, 32), dtype=np.uint8)
+        check(lib().et_graph_result_fr(self._h, _ptr(out), stream))
+        return out
+
+    def result_f64(self, stream=None):
+        out = np.zeros(self.n, dtype=np.float64)
+        check(lib().et_graph_result_f64(self._h, _ptr(out), stream))
+        return out
+
+    def stats_fr(self, iteration, stream=None):
+        st = _ffi.EtIterStats()
+        check(lib().et_graph_stats_fr(self._h, iteration, stream, C.byref(st)))
+        return int.from_bytes(bytes(st.sum.b), "little"), st.changed
+
+    def stats_f64(self, iteration, stream=None):
+        st = _ffi.EtIterStats()
+        check(lib().et_graph_stats_f64(self._h, iteration, stream, C.byref(st)))
+        return st.residual_l1, st.sum_f64
+
+    # stepping on caller-owned device vectors (raw device pointers as ints) ---------------------
+    def init_fr(self, x_ptr, initial=1000, stream=None):
+        check(lib().et_graph_init_fr_async(self._h, initial & (2**64 - 1), initial >> 64, x_ptr, stream))
+
+    def init_f64(self, x_ptr, initial=1000.0, stream=None):
+        check(lib().et_graph_init_f64_async(self._h, initial, x_ptr, stream))
+
+    def step_fr(self, x_ptr, y_ptr, iteration, stream=None):
+        check(lib().et_graph_step_fr_async(self._h, x_ptr, y_ptr, iteration, stream))
+
+    def step_f64(self, x_ptr, y_ptr, iteration, alpha=0.0, pretrust_ptr=None, stream=None):
+        check(lib().et_graph_step_f64_async(self._h, x_ptr, y_ptr, iteration, alpha, pretrust_ptr, stream))
+
+    def unpermute_fr(self, x_ptr, out_ptr, stream=None):
+        check(lib().et_graph_unpermute_fr_async(self._h, x_ptr, out_ptr, stream))
+
+    def unpermute_f64(self, x_ptr, out_ptr, stream=None):
+        check(lib().et_graph_unpermute_f64_async(self._h, x_ptr, out_ptr, stream))
