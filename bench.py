@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Benchmark of the EigenTrust convergence hot path on MI355X.
+
+A "step" is one whole converge on a device-resident graph: initial vector, NUM_ITERATIONS = 20
+iteration launches (dynamic_sets/native.rs:319-329), result back in slot order.  Inputs are
+synthetic (the reference never runs above a dozen peers) and already resident in HBM when the timed
+region starts.
+
+  N = 1   : 1 048 576 peers, 16 777 216 attestations, power-law out-degree (the configuration the
+            metric is quoted on); f64 and Fr-exact variants are both timed, `value` is the f64 one.
+  N > 1   : 16 777 216 peers, 268 435 456 attestations row-sharded over the N GPUs, one all-gather
+            of the trust vector per iteration (torch.distributed, backend nccl = RCCL).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NUM_ITER = 20
+INITIAL = 1000
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+WORKLOADS = {
+    # name: (kind, peers, attestations, description)
+    "c2": (2, 1 << 16, 1 << 20, "64K peers / 1M attestations, uniform out-degree 16"),
+    "c3": (3, 1 << 20, 1 << 24, "1M peers / 16M attestations, power-law out-degree, 1% dangling"),
+    "c4": (3, 1 << 24, 1 << 28, "16M peers / 256M attestations, power-law out-degree, 1% dangling"),
+}
+
+
+def algorithmic_bytes(variant, nnz, rows):
+    """Bytes one iteration launch must move when every array is touched once (CSR of C^T with
+    pre-normalised weights): f64 nnz*(8+4) + rows*(4+8+8); Fr nnz*(32+4) + rows*(4+32+32)."""
+    if variant == "f64":
+        return nnz * 12 + rows * 20
+    return nnz * 36 + rows * 68
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "c4"])
+    ap.add_argument("--variant", default="both", choices=["both", "f64", "fr"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=42)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import protocol_amd as pa
+    from protocol_amd.sharded import ShardedGraph
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    wl = args.workload
+    if wl == "auto":
+        wl = "c3" if world == 1 else "c4"
+    kind, n, target_edges, desc = WORKLOADS[wl]
+
+    t0 = time.time()
+    frm, to, val = pa.synth_graph(kind, n, target_edges, seed=args.seed, value_max=255)
+    t_gen = time.time() - t0
+    variants = {"both": 3, "fr": 1, "f64": 2}[args.variant]
+    t0 = time.time()
+    sg = ShardedGraph(n, frm, to, value_u32=val, device=device, variants=variants)
+    t_build = time.time() - t0
+    info = sg.graph.info
+    nnz = int(info.nnz)
+    if world > 1:
+        del frm, to, val  # the host copy is not needed after upload
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    results = {}
+    for variant in (["f64", "fr"] if args.variant == "both" else [args.variant]):
+        if variant == "f64":
+            def run(rec):
+                return sg.run_f64(NUM_ITER, float(INITIAL), 0.0, record=rec)
+        else:
+            def run(rec):
+                return sg.run_fr(NUM_ITER, INITIAL, record=rec)
+        for _ in range(args.warmup):
+            run(False)
+        barrier()
+        sg.graph.event_times()  # empty the event ring
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run(True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        ev_ms, ev_pairs = sg.graph.event_times()
+        launches = ev_pairs * (NUM_ITER if world == 1 else 1)
+        # world == 1 brackets the 20 back-to-back launches of a step with one pair of events;
+        # the sharded loop brackets every launch (an all-gather sits between launches)
+        launch_s = ev_ms * 1e-3 / max(1, launches)
+        rows_local = int(info.n_valid) // world
+        alg = algorithmic_bytes(variant, int(info.nnz_local), rows_local)
+        achieved = alg / launch_s / 1e9
+        results[variant] = {
+            "value": nnz * NUM_ITER * args.steps / elapsed,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_step_f64" if variant == "f64" else "k_step_fr",
+                         "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": alg},
+        }
+
+    # parity of the timed configuration: conservation of the score sum (native.rs:331-334)
+    checks = {}
+    st = torch.cuda.current_stream(device).cuda_stream
+    if "fr" in results:
+        s, changed = sg.graph.stats_fr(NUM_ITER - 1, st)
+        total = sg._sum_mod_r(s)
+        checks["fr_sum_conserved"] = bool(total == INITIAL * int(info.n_valid) % pa.R_MODULUS)
+    if "f64" in results:
+        res, s64 = sg.graph.stats_f64(NUM_ITER - 1, st)
+        if world > 1:
+            t = torch.tensor([res, s64], dtype=torch.float64, device=device)
+            dist.all_reduce(t)
+            res, s64 = float(t[0]), float(t[1])
+        checks["f64_sum_rel_err"] = abs(s64 - INITIAL * float(info.n_valid)) / (INITIAL * float(info.n_valid))
+        checks["f64_residual_l1"] = res
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the CPU checker (a port: the reference is Rust and cannot be built in this image),
+        # timed on this box's host cores over the same graph and the same 20 iterations
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import c_oracle
+        threads = c_oracle.max_threads()
+        member = np.ones(n, dtype=np.uint8)
+        cpu = {"unit": "edge-iterations/s", "cores": threads, "kind": "port",
+               "sample": "%s, %d iterations, OpenMP over rows, iteration loop only" % (wl, NUM_ITER)}
+        if "f64" in results:
+            rc, _o, _l, _r, cnnz, secs = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=NUM_ITER,
+                                                                       initial=float(INITIAL), n_threads=threads)
+            assert rc == 0 and cnnz == nnz
+            cpu["value"] = cnnz * NUM_ITER / secs
+        if "fr" in results:
+            rc, _o, cnnz, secs = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=NUM_ITER,
+                                                             initial=INITIAL, n_threads=threads)
+            assert rc == 0 and cnnz == nnz
+            cpu["fr_value"] = cnnz * NUM_ITER / secs
+            if "value" not in cpu:
+                cpu["value"] = cpu["fr_value"]
+
+    if rank == 0:
+        head = results.get("f64") or results["fr"]
+        line = {
+            "metric": "edge-iterations/sec", "value": head["value"], "unit": "edge-iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
+            "dtype": "f64" if "f64" in results else "fr254", "data": "synthetic",
+            "config": {"workload": "%s: %s; %d iterations per step; pre-normalised weights" % (wl, desc, NUM_ITER),
+                       "peers": n, "edges": nnz, "iterations": NUM_ITER, "parallelism": "rows sharded x%d" % world,
+                       "seed": args.seed},
+            "roofline": head["roofline"],
+            "cpu_baseline": cpu,
+            "checks": checks,
+            "setup_s": {"generate": t_gen, "build_and_upload": t_build},
+        }
+        if "fr" in results and "f64" in results:
+            line["fr_exact"] = dict(results["fr"], dtype="fr254 (8x32-bit limbs)", unit="edge-iterations/s")
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -187,13 +187,19 @@ int et_graph_stats_fr(et_graph *g, uint32_t iteration, void *stream, et_iter_sta
 int et_graph_stats_f64(et_graph *g, uint32_t iteration, void *stream, et_iter_stats *out);
 
 /* Runs init + num_iterations steps + unpermute back to back on `stream` with the graph's own
- * double-buffered vectors (n_seg must be 1); leaves the slot-order result on the device.  When
- * step_ms is not NULL the iteration launches are bracketed by HIP events and the elapsed time of
- * the num_iterations launches is returned (this synchronises the stream). */
+ * double-buffered vectors (n_seg must be 1); leaves the slot-order result on the device and does
+ * not synchronise.  With record_events != 0 the iteration launches are bracketed by a pair of HIP
+ * events taken from a ring of 1024 pairs (see et_graph_event_times). */
 int et_graph_run_fr(et_graph *g, uint32_t num_iterations, uint64_t initial_lo, uint64_t initial_hi,
-                    void *stream, float *step_ms);
+                    void *stream, int record_events);
 int et_graph_run_f64(et_graph *g, uint32_t num_iterations, double initial, double alpha,
-                     void *stream, float *step_ms);
+                     void *stream, int record_events);
+/* The same bracketing for callers that issue et_graph_step_* themselves. */
+int et_graph_record_begin(et_graph *g, void *stream);
+int et_graph_record_end(et_graph *g, void *stream);
+/* Waits for every recorded pair, returns the sum of their elapsed times and their number, and
+ * empties the ring. */
+int et_graph_event_times(et_graph *g, float *total_ms, uint32_t *pairs);
 /* Copies the result of the last et_graph_run_* to the host (n entries, slot order). */
 int et_graph_result_fr(et_graph *g, et_fr *out, void *stream);
 int et_graph_result_f64(et_graph *g, double *out, void *stream);

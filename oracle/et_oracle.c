@@ -246,10 +246,23 @@ static int sg_build(sparse_graph *g, uint32_t n, const uint8_t *member, uint64_t
     }
     g->dangling = (uint8_t *)calloc(n, 1);
     fe *inv = (fe *)calloc(n, sizeof(fe));
-    for (uint32_t i = 0; i < n; ++i) {
-        if (!member[i]) continue;
-        if (fe_is_zero(sum_fr[i])) g->dangling[i] = 1;   /* native.rs:264: row of ones */
-        else inv[i] = fe_inv(sum_fr[i]);
+    {
+        /* one field inversion for all rows (prefix products), same values as inverting each sum */
+        fe *pre = (fe *)malloc((size_t)n * sizeof(fe));
+        fe run = fe_from_u64(1);
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!member[i]) continue;
+            if (fe_is_zero(sum_fr[i])) { g->dangling[i] = 1; continue; }   /* native.rs:264: row of ones */
+            pre[i] = run;
+            run = fe_mul(run, sum_fr[i]);
+        }
+        fe back = fe_inv(run);
+        for (uint32_t i = n; i-- > 0;) {
+            if (!member[i] || g->dangling[i]) continue;
+            inv[i] = fe_mul(back, pre[i]);
+            back = fe_mul(back, sum_fr[i]);
+        }
+        free(pre);
     }
     /* transpose to CSR by destination; edges of dangling sources are replaced by the row of ones */
     g->rowptr = (uint64_t *)calloc((size_t)n + 2, sizeof(uint64_t));

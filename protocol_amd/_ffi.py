@@ -83,8 +83,11 @@ PROTOTYPES = {
     "et_graph_permute_f64_host": (i32, [vp, vp, vp]),
     "et_graph_stats_fr": (i32, [vp, u32, vp, P(EtIterStats)]),
     "et_graph_stats_f64": (i32, [vp, u32, vp, P(EtIterStats)]),
-    "et_graph_run_fr": (i32, [vp, u32, u64, u64, vp, P(C.c_float)]),
-    "et_graph_run_f64": (i32, [vp, u32, dbl, dbl, vp, P(C.c_float)]),
+    "et_graph_run_fr": (i32, [vp, u32, u64, u64, vp, i32]),
+    "et_graph_run_f64": (i32, [vp, u32, dbl, dbl, vp, i32]),
+    "et_graph_record_begin": (i32, [vp, vp]),
+    "et_graph_record_end": (i32, [vp, vp]),
+    "et_graph_event_times": (i32, [vp, P(C.c_float), P(u32)]),
     "et_graph_result_fr": (i32, [vp, vp, vp]),
     "et_graph_result_f64": (i32, [vp, vp, vp]),
     "et_synth_graph": (i32, [u32, u32, u64, u64, u32, P(u64), vp, vp, vp]),

@@ -106,7 +106,7 @@ int et_graph_converge_fr(et_graph* g, uint32_t num_iterations, uint64_t initial_
     if (!g || !out) return ET_E_INVALID_ARG;
     DeviceGraph* d = G(g);
     HIP_TRY_C(hipSetDevice(d->device));
-    int rc = d->run_fr(num_iterations, initial_lo, initial_hi, nullptr, nullptr);
+    int rc = d->run_fr(num_iterations, initial_lo, initial_hi, nullptr, false);
     if (rc) return rc;
     if ((rc = et_graph_result_fr(g, out, nullptr))) return rc;
     // conservation (native.rs:331-334): sum of the initial scores == sum of the final scores
@@ -141,7 +141,7 @@ int et_graph_converge_f64(et_graph* g, uint32_t num_iterations, double initial, 
             if ((rc = d->step_f64(d->vx[it & 1], d->vx[(it + 1) & 1], it, alpha, d->d_pretrust, nullptr))) return rc;
         if ((rc = d->unpermute_f64(d->vx[num_iterations & 1], d->out_f64, nullptr))) return rc;
     } else {
-        if ((rc = d->run_f64(num_iterations, initial, alpha, nullptr, nullptr))) return rc;
+        if ((rc = d->run_f64(num_iterations, initial, alpha, nullptr, false))) return rc;
     }
     if ((rc = et_graph_result_f64(g, out, nullptr))) return rc;
     if (residual_l1) {
@@ -196,13 +196,25 @@ int et_graph_stats_f64(et_graph* g, uint32_t iteration, void* stream, et_iter_st
     if (!g || !out) return ET_E_INVALID_ARG;
     return G(g)->stats_f64(iteration, (hipStream_t)stream, out);
 }
-int et_graph_run_fr(et_graph* g, uint32_t num_iterations, uint64_t lo, uint64_t hi, void* stream, float* step_ms) {
+int et_graph_run_fr(et_graph* g, uint32_t num_iterations, uint64_t lo, uint64_t hi, void* stream, int record_events) {
     if (!g) return ET_E_INVALID_ARG;
-    return G(g)->run_fr(num_iterations, lo, hi, (hipStream_t)stream, step_ms);
+    return G(g)->run_fr(num_iterations, lo, hi, (hipStream_t)stream, record_events != 0);
 }
-int et_graph_run_f64(et_graph* g, uint32_t num_iterations, double initial, double alpha, void* stream, float* step_ms) {
+int et_graph_run_f64(et_graph* g, uint32_t num_iterations, double initial, double alpha, void* stream, int record_events) {
     if (!g) return ET_E_INVALID_ARG;
-    return G(g)->run_f64(num_iterations, initial, alpha, (hipStream_t)stream, step_ms);
+    return G(g)->run_f64(num_iterations, initial, alpha, (hipStream_t)stream, record_events != 0);
+}
+int et_graph_record_begin(et_graph* g, void* stream) {
+    if (!g) return ET_E_INVALID_ARG;
+    return G(g)->record_begin((hipStream_t)stream);
+}
+int et_graph_record_end(et_graph* g, void* stream) {
+    if (!g) return ET_E_INVALID_ARG;
+    return G(g)->record_end((hipStream_t)stream);
+}
+int et_graph_event_times(et_graph* g, float* total_ms, uint32_t* pairs) {
+    if (!g) return ET_E_INVALID_ARG;
+    return G(g)->event_times(total_ms, pairs);
 }
 int et_graph_result_fr(et_graph* g, et_fr* out, void* stream) {
     if (!g || !out) return ET_E_INVALID_ARG;

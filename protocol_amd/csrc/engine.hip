@@ -439,8 +439,8 @@ DeviceGraph::~DeviceGraph() {
     void* ptrs[] = {d_blocks, d_slices, d_col, d_w64, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
                     d_chg_part, d_stat_out, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (ev0) (void)hipEventDestroy((hipEvent_t)ev0);
-    if (ev1) (void)hipEventDestroy((hipEvent_t)ev1);
+    for (void* e : ev_begin) (void)hipEventDestroy((hipEvent_t)e);
+    for (void* e : ev_end) (void)hipEventDestroy((hipEvent_t)e);
 }
 
 static U256 to_u256(const FrRaw& r) {
@@ -516,10 +516,6 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     free_tmp();
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    g->ev0 = e0; g->ev1 = e1;
     *out = g.release();
     return ET_OK;
 }
@@ -612,7 +608,38 @@ int DeviceGraph::stats_fr(uint32_t iteration, hipStream_t st, et_iter_stats* out
     return ET_OK;
 }
 
-int DeviceGraph::run_f64(uint32_t iters, double initial, double alpha, hipStream_t st, float* step_ms) {
+int DeviceGraph::record_begin(hipStream_t st) {
+    if (ev_count >= EVENT_RING) { set_error("event ring full: call et_graph_event_times"); return ET_E_UNSUPPORTED; }
+    if (ev_begin.size() <= ev_count) {
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        ev_begin.push_back(e0);
+        ev_end.push_back(e1);
+    }
+    HIP_TRY(hipEventRecord((hipEvent_t)ev_begin[ev_count], st));
+    return ET_OK;
+}
+int DeviceGraph::record_end(hipStream_t st) {
+    HIP_TRY(hipEventRecord((hipEvent_t)ev_end[ev_count], st));
+    ++ev_count;
+    return ET_OK;
+}
+int DeviceGraph::event_times(float* total_ms, uint32_t* pairs) {
+    float total = 0.f;
+    for (uint32_t i = 0; i < ev_count; ++i) {
+        HIP_TRY(hipEventSynchronize((hipEvent_t)ev_end[i]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)ev_begin[i], (hipEvent_t)ev_end[i]));
+        total += ms;
+    }
+    if (total_ms) *total_ms = total;
+    if (pairs) *pairs = ev_count;
+    ev_count = 0;
+    return ET_OK;
+}
+
+int DeviceGraph::run_f64(uint32_t iters, double initial, double alpha, hipStream_t st, bool record) {
     if (geo.n_seg != 1) { set_error("run needs the whole graph on one GPU"); return ET_E_UNSUPPORTED; }
     int rc = init_f64(initial, vx[0], st);
     if (rc) return rc;
@@ -627,32 +654,24 @@ int DeviceGraph::run_f64(uint32_t iters, double initial, double alpha, hipStream
         HIP_TRY(hipMemcpyAsync(d_pretrust, vx[0], vec_len * sizeof(double), hipMemcpyDeviceToDevice, st));
         pre = d_pretrust;
     }
-    if (step_ms) HIP_TRY(hipEventRecord((hipEvent_t)ev0, st));
+    if (record && (rc = record_begin(st))) return rc;
     for (uint32_t it = 0; it < iters; ++it)
         if ((rc = step_f64(vx[it & 1], vx[(it + 1) & 1], it, alpha, pre, st))) return rc;
-    if (step_ms) HIP_TRY(hipEventRecord((hipEvent_t)ev1, st));
+    if (record && (rc = record_end(st))) return rc;
     if ((rc = unpermute_f64(vx[iters & 1], out_f64, st))) return rc;
     last_iters = iters;
-    if (step_ms) {
-        HIP_TRY(hipEventSynchronize((hipEvent_t)ev1));
-        HIP_TRY(hipEventElapsedTime(step_ms, (hipEvent_t)ev0, (hipEvent_t)ev1));
-    }
     return ET_OK;
 }
-int DeviceGraph::run_fr(uint32_t iters, uint64_t lo, uint64_t hi, hipStream_t st, float* step_ms) {
+int DeviceGraph::run_fr(uint32_t iters, uint64_t lo, uint64_t hi, hipStream_t st, bool record) {
     if (geo.n_seg != 1) { set_error("run needs the whole graph on one GPU"); return ET_E_UNSUPPORTED; }
     int rc = init_fr(lo, hi, fx[0], st);
     if (rc) return rc;
-    if (step_ms) HIP_TRY(hipEventRecord((hipEvent_t)ev0, st));
+    if (record && (rc = record_begin(st))) return rc;
     for (uint32_t it = 0; it < iters; ++it)
         if ((rc = step_fr(fx[it & 1], fx[(it + 1) & 1], it, st))) return rc;
-    if (step_ms) HIP_TRY(hipEventRecord((hipEvent_t)ev1, st));
+    if (record && (rc = record_end(st))) return rc;
     if ((rc = unpermute_fr(fx[iters & 1], out_fr, st))) return rc;
     last_iters = iters;
-    if (step_ms) {
-        HIP_TRY(hipEventSynchronize((hipEvent_t)ev1));
-        HIP_TRY(hipEventElapsedTime(step_ms, (hipEvent_t)ev0, (hipEvent_t)ev1));
-    }
     return ET_OK;
 }
 

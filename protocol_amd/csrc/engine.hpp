@@ -46,8 +46,10 @@ struct DeviceGraph {
     double* out_f64 = nullptr;
     uint4* out_fr = nullptr;
     double* d_pretrust = nullptr;
-    void* ev0 = nullptr;
-    void* ev1 = nullptr;
+    // ring of HIP event pairs bracketing the iteration launches of timed runs
+    static const uint32_t EVENT_RING = 1024;
+    std::vector<void*> ev_begin, ev_end;
+    uint32_t ev_count = 0;
 
     ~DeviceGraph();
     static int create(const HostGraph& h, int variants, int device, DeviceGraph** out);
@@ -60,8 +62,11 @@ struct DeviceGraph {
     int unpermute_fr(const uint4* x, uint4* out, hipStream_t st);
     int stats_f64(uint32_t iteration, hipStream_t st, et_iter_stats* out);
     int stats_fr(uint32_t iteration, hipStream_t st, et_iter_stats* out);
-    int run_f64(uint32_t iters, double initial, double alpha, hipStream_t st, float* step_ms);
-    int run_fr(uint32_t iters, uint64_t lo, uint64_t hi, hipStream_t st, float* step_ms);
+    int run_f64(uint32_t iters, double initial, double alpha, hipStream_t st, bool record);
+    int run_fr(uint32_t iters, uint64_t lo, uint64_t hi, hipStream_t st, bool record);
+    int record_begin(hipStream_t st);
+    int record_end(hipStream_t st);
+    int event_times(float* total_ms, uint32_t* pairs);
 };
 
 int dev_fr_mul(uint32_t count, const et_fr* a, const et_fr* b, et_fr* out);

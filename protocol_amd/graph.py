@@ -91,16 +91,24 @@ class Graph:
         return out, res.value
 
     # device-resident runs ------------------------------------------------------------------------
-    def run_fr(self, num_iterations=20, initial=1000, stream=None, timed=False):
-        ms = C.c_float(0)
-        check(lib().et_graph_run_fr(self._h, num_iterations, initial & (2**64 - 1), initial >> 64, stream,
-                                    C.byref(ms) if timed else None))
-        return ms.value
+    def run_fr(self, num_iterations=20, initial=1000, stream=None, record=False):
+        check(lib().et_graph_run_fr(self._h, num_iterations, initial & (2**64 - 1), initial >> 64, stream, int(record)))
 
-    def run_f64(self, num_iterations=20, initial=1000.0, alpha=0.0, stream=None, timed=False):
+    def run_f64(self, num_iterations=20, initial=1000.0, alpha=0.0, stream=None, record=False):
+        check(lib().et_graph_run_f64(self._h, num_iterations, initial, alpha, stream, int(record)))
+
+    def record_begin(self, stream=None):
+        check(lib().et_graph_record_begin(self._h, stream))
+
+    def record_end(self, stream=None):
+        check(lib().et_graph_record_end(self._h, stream))
+
+    def event_times(self):
+        """(total ms between the recorded event pairs, number of pairs); empties the ring."""
         ms = C.c_float(0)
-        check(lib().et_graph_run_f64(self._h, num_iterations, initial, alpha, stream, C.byref(ms) if timed else None))
-        return ms.value
+        n = C.c_uint32(0)
+        check(lib().et_graph_event_times(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def result_fr(self, stream=None):
         out = np.zeros((self.n, 32), dtype=np.uint8)

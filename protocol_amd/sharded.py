@@ -1,0 +1,152 @@
+"""Row-sharded multi-GPU converge: one process per GPU, torch.distributed (RCCL) for the exchange.
+
+Every rank holds the rows (destination peers) of its segment plus a full-length trust vector.
+Per iteration a rank runs the step kernel on its rows, which writes its segment of the new vector
+and, in the segment's tail, its partial sums of the dangling-peer score mass; one in-place
+all-gather of the segments then gives every rank the whole new vector and every partial sum.
+That all-gather is the only collective on the path.
+
+Segments are dealt 64 rows at a time round-robin in degree order, so every rank gets the same number
+of rows and a near-identical degree mix; results do not depend on the number of ranks (the Fr
+variant is exact integer arithmetic; the f64 variant sums each row on one rank in a fixed order and
+combines partial sums in a fixed order).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _ffi
+from .graph import Graph, R_MODULUS
+
+
+class ShardedGraph:
+    def __init__(self, n, frm, to, value_u32=None, value_fr=None, member=None, group=None,
+                 device=None, variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64, **build_kw):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.graph = Graph(n, frm, to, value_u32=value_u32, value_fr=value_fr, member=member,
+                           n_seg=self.world, seg=self.rank, variants=variants,
+                           device=self.device.index if self.device.index is not None else -1, **build_kw)
+        info = self.graph.info
+        self.n = n
+        self.vec_len = int(info.vec_len)
+        self.seg_stride = int(info.rows_cap + info.nd_cap)
+        assert self.vec_len == self.seg_stride * self.world
+        self.nnz = int(info.nnz)
+        self.n_valid = int(info.n_valid)
+        self._vec = {}
+
+    # ---- buffers ---------------------------------------------------------------------------------
+    def _buffers(self, kind):
+        if kind not in self._vec:
+            if kind == "f64":
+                mk = lambda: torch.zeros(self.vec_len, dtype=torch.float64, device=self.device)
+                out = torch.zeros(self.n, dtype=torch.float64, device=self.device)
+            else:  # field elements: 4 x int64 per entry
+                mk = lambda: torch.zeros((self.vec_len, 4), dtype=torch.int64, device=self.device)
+                out = torch.zeros((self.n, 4), dtype=torch.int64, device=self.device)
+            self._vec[kind] = (mk(), mk(), out)
+        return self._vec[kind]
+
+    def _segment(self, t):
+        return t[self.rank * self.seg_stride:(self.rank + 1) * self.seg_stride]
+
+    def _all_gather(self, t):
+        """In-place all-gather of the segments of `t`."""
+        if self.world == 1:
+            return
+        backend = dist.get_backend(self.group)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(t, self._segment(t), group=self.group)
+        else:  # gloo (CPU rendezvous, used by tests): stage through host memory
+            mine = self._segment(t).cpu().contiguous()
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine, group=self.group)
+            for r, p in enumerate(parts):
+                if r != self.rank:
+                    t[r * self.seg_stride:(r + 1) * self.seg_stride].copy_(p)
+
+    # ---- converge --------------------------------------------------------------------------------
+    def run_f64(self, num_iterations=20, initial=1000.0, alpha=0.0, record=False):
+        """Enqueues a whole converge; the slot-order result stays on the device (result_f64)."""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        g = self.graph
+        if self.world == 1:  # no exchange step: the library's own back-to-back loop
+            g.run_f64(num_iterations, initial, alpha, st, record)
+            return
+        x, y, out = self._buffers("f64")
+        g.init_f64(x.data_ptr(), initial, st)
+        self._all_gather(x)
+        pre = None
+        if alpha != 0.0:
+            if "pre" not in self._vec:
+                self._vec["pre"] = torch.empty_like(x)
+            self._vec["pre"].copy_(x)
+            pre = self._vec["pre"].data_ptr()
+        bufs = (x, y)
+        for it in range(num_iterations):
+            a, b = bufs[it & 1], bufs[(it + 1) & 1]
+            if record:
+                g.record_begin(st)
+            g.step_f64(a.data_ptr(), b.data_ptr(), it, alpha, pre, st)
+            if record:
+                g.record_end(st)
+            self._all_gather(b)
+        g.unpermute_f64(bufs[num_iterations & 1].data_ptr(), out.data_ptr(), st)
+
+    def run_fr(self, num_iterations=20, initial=1000, record=False):
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        g = self.graph
+        if self.world == 1:
+            g.run_fr(num_iterations, initial, st, record)
+            return
+        x, y, out = self._buffers("fr")
+        g.init_fr(x.data_ptr(), initial, st)
+        self._all_gather(x)
+        bufs = (x, y)
+        for it in range(num_iterations):
+            a, b = bufs[it & 1], bufs[(it + 1) & 1]
+            if record:
+                g.record_begin(st)
+            g.step_fr(a.data_ptr(), b.data_ptr(), it, st)
+            if record:
+                g.record_end(st)
+            self._all_gather(b)
+        g.unpermute_fr(bufs[num_iterations & 1].data_ptr(), out.data_ptr(), st)
+
+    def result_f64(self):
+        torch.cuda.synchronize(self.device)
+        if self.world == 1:
+            return self.graph.result_f64(torch.cuda.current_stream(self.device).cuda_stream)
+        return self._buffers("f64")[2].cpu().numpy()
+
+    def result_fr(self):
+        torch.cuda.synchronize(self.device)
+        if self.world == 1:
+            return self.graph.result_fr(torch.cuda.current_stream(self.device).cuda_stream)
+        return self._buffers("fr")[2].cpu().numpy().view(np.uint8).reshape(self.n, 32)
+
+    def converge_fr(self, num_iterations=20, initial=1000):
+        """Scores of all n slots as a uint8 array [n, 32]; checks conservation across ranks
+        (dynamic_sets/native.rs:331-334)."""
+        self.run_fr(num_iterations, initial)
+        res = self.result_fr()
+        if num_iterations > 0:
+            s, _changed = self.graph.stats_fr(num_iterations - 1, torch.cuda.current_stream(self.device).cuda_stream)
+            total = self._sum_mod_r(s)
+            if total != initial * self.n_valid % R_MODULUS:
+                raise _ffi.EigenTrustError(_ffi.ET_E_SUM_MISMATCH, "field sum of scores changed")
+        return res
+
+    def converge_f64(self, num_iterations=20, initial=1000.0, alpha=0.0):
+        self.run_f64(num_iterations, initial, alpha)
+        return self.result_f64()
+
+    def _sum_mod_r(self, mine):
+        if self.world == 1:
+            return mine % R_MODULUS
+        parts = [None] * self.world
+        dist.all_gather_object(parts, int(mine), group=self.group)
+        return sum(parts) % R_MODULUS
