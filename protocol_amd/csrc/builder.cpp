@@ -304,7 +304,7 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
             g.blocks.push_back(bd);
         }
     };
-    const uint32_t target = opt.target_blocks ? opt.target_blocks : 1024;
+    const uint32_t target = opt.target_blocks ? opt.target_blocks : 2048;
     partition(0, first_dang, target, false);
     size_t nb_active = g.blocks.size();
     partition(first_dang, n_slices, geo.nd_cap, true);

@@ -34,7 +34,7 @@ struct BuildOpts {
     uint32_t n_seg = 1;          // GPUs sharing the rows
     uint32_t seg = 0;            // this GPU
     uint32_t long_row = 128;     // in-degree above which a row is spread over a whole wavefront
-    uint32_t target_blocks = 1024;
+    uint32_t target_blocks = 2048;
     uint32_t nd_cap = 32;        // partial-sum slots per segment (>= workgroups holding dangling rows)
 };
 

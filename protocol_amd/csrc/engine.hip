@@ -154,24 +154,48 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step_f64(StepArgsF64 a) {
     }
     const double dterm = D * a.inv_nm1;
 
+    const double* __restrict__ xr = a.x;
     double res = 0.0, tot = 0.0, dacc = 0.0;
     for (uint32_t s = bd.slice_begin + wave; s < bd.slice_end; s += WAVES_PER_BLOCK) {
         const SliceDesc sd = a.slices[s];
         const uint32_t* __restrict__ cp = a.col + (size_t)sd.off * 64 + lane;
         const double* __restrict__ wp = a.w + (size_t)sd.off * 64 + lane;
-        double acc = 0.0;
-#pragma unroll 4
-        for (uint32_t k = 0; k < sd.len; ++k) {
-            uint32_t c = cp[(size_t)k * 64];
-            double w = wp[(size_t)k * 64];
-            acc = fma(w, a.x[c], acc);
-        }
         const bool reduce = (sd.nrows & SLICE_REDUCE) != 0;
-        if (reduce) acc = wave_sum_f64(acc);
         const uint32_t row = reduce ? sd.row0 : sd.row0 + lane;
         const bool live = reduce ? lane == 0 : (uint32_t)lane < (sd.nrows & 0xFFu);
+        // the row's current score is needed only in the epilogue: issue its load first
+        double old = 0.0;
+        if (live) old = xr[my_base + row];
+        double acc = 0.0;
+        {
+            // Batches of U steps; the source indices of batch b+1 are requested before batch b's
+            // products are formed, so a wave keeps about 3*U loads in flight.  The last batch may
+            // be partial: its surplus steps re-read the slice's last step (an L1 hit) with the
+            // weight forced to zero, which keeps the loop free of per-step branches.
+            constexpr int U = 4;
+            const uint32_t len = sd.len;
+            if (len > 0) {
+                const uint32_t last = len - 1;
+                uint32_t c[U];
+#pragma unroll
+                for (int i = 0; i < U; ++i) c[i] = cp[(size_t)min((uint32_t)i, last) * 64];
+                for (uint32_t k = 0; k < len; k += U) {
+                    double w[U], xv[U];
+#pragma unroll
+                    for (int i = 0; i < U; ++i) w[i] = wp[(size_t)min(k + i, last) * 64];
+#pragma unroll
+                    for (int i = 0; i < U; ++i) xv[i] = xr[c[i]];
+                    if (k + U < len) {
+#pragma unroll
+                        for (int i = 0; i < U; ++i) c[i] = cp[(size_t)min(k + U + i, last) * 64];
+                    }
+#pragma unroll
+                    for (int i = 0; i < U; ++i) acc = fma(k + i < len ? w[i] : 0.0, xv[i], acc);
+                }
+            }
+        }
+        if (reduce) acc = wave_sum_f64(acc);
         if (live) {
-            double old = a.x[my_base + row];
             double v = dang ? acc + (D - old) * a.inv_nm1 : acc + dterm;
             if (HAS_ALPHA) {
                 double p = a.pretrust[my_base + row];
