@@ -149,6 +149,33 @@ int et_graph_build(uint32_t n, const uint8_t *member, uint64_t n_edges, const ui
 void et_graph_free(et_graph *g);
 int et_graph_info_get(const et_graph *g, et_graph_info *info);
 
+/* ---- host-side plan (no GPU needed): the layout et_graph_build uploads ----------------------
+ * Lets a caller (or a test) inspect how an attestation list was filtered, ordered, sliced and
+ * split over segments.  Arrays stay owned by the plan. */
+typedef struct et_plan et_plan;
+typedef struct { uint32_t off, len, row0, nrows; } et_slice_desc;   /* nrows bit 31: wavefront-reduced row */
+typedef struct { uint32_t slice_begin, slice_end, flags, dslot; } et_block_desc; /* flags bit 0: dangling rows */
+typedef struct {
+    const uint32_t *pos_of_slot;      /* n: position of each slot's peer, 0xFFFFFFFF for empty slots  */
+    const et_slice_desc *slices;      /* n_slices                                                      */
+    const et_block_desc *blocks;      /* n_blocks                                                      */
+    const uint32_t *col;              /* padded_local source positions (step-major, 64 lanes a step)   */
+    const uint32_t *value_u32;        /* padded_local raw opinions, or NULL                            */
+    const et_fr *value_fr;            /* padded_local raw opinions, or NULL                            */
+    const et_fr *scale_fr;            /* vec_len: inv(row sum) * 2^576 mod r per source position       */
+    const double *scale_f64;          /* vec_len: 1 / integer row sum per source position              */
+    et_fr inv_nm1_w;                  /* inv(n_valid - 1) * 2^288 mod r                                */
+    uint32_t n_active, n_active_pad, n_dangling_pad, n_dangling_local;
+} et_plan_arrays;
+int et_plan_build(uint32_t n, const uint8_t *member, uint64_t n_edges, const uint32_t *from,
+                  const uint32_t *to, const uint32_t *value_u32, const et_fr *value_fr,
+                  const et_build_opts *opts, et_plan **out);
+void et_plan_free(et_plan *p);
+int et_plan_info_get(const et_plan *p, et_graph_info *info);   /* device_bytes = 0 */
+int et_plan_arrays_get(const et_plan *p, et_plan_arrays *out);
+/* Uploads a plan (what et_graph_build does after planning). */
+int et_graph_from_plan(const et_plan *p, const et_build_opts *opts, et_graph **out);
+
 /* Whole converge on this graph (n_seg must be 1): scores for all n slots in slot order. */
 int et_graph_converge_fr(et_graph *g, uint32_t num_iterations, uint64_t initial_lo,
                          uint64_t initial_hi, et_fr *out);

@@ -45,6 +45,23 @@ class EtGraphInfo(C.Structure):
                 ("vec_len", C.c_uint64), ("device_bytes", C.c_uint64)]
 
 
+class EtSliceDesc(C.Structure):
+    _fields_ = [("off", C.c_uint32), ("len", C.c_uint32), ("row0", C.c_uint32), ("nrows", C.c_uint32)]
+
+
+class EtBlockDesc(C.Structure):
+    _fields_ = [("slice_begin", C.c_uint32), ("slice_end", C.c_uint32), ("flags", C.c_uint32), ("dslot", C.c_uint32)]
+
+
+class EtPlanArrays(C.Structure):
+    _fields_ = [("pos_of_slot", C.POINTER(C.c_uint32)), ("slices", C.POINTER(EtSliceDesc)),
+                ("blocks", C.POINTER(EtBlockDesc)), ("col", C.POINTER(C.c_uint32)),
+                ("value_u32", C.POINTER(C.c_uint32)), ("value_fr", C.POINTER(EtFr)),
+                ("scale_fr", C.POINTER(EtFr)), ("scale_f64", C.POINTER(C.c_double)),
+                ("inv_nm1_w", EtFr), ("n_active", C.c_uint32), ("n_active_pad", C.c_uint32),
+                ("n_dangling_pad", C.c_uint32), ("n_dangling_local", C.c_uint32)]
+
+
 class EtIterStats(C.Structure):
     _fields_ = [("sum", EtFr), ("changed", C.c_uint64), ("residual_l1", C.c_double),
                 ("sum_f64", C.c_double)]
@@ -70,6 +87,11 @@ PROTOTYPES = {
     "et_set_converge_f64": (i32, [vp, dbl, vp, vp, P(dbl)]),
     "et_set_converge_rational": (i32, [vp, vp, vp, C.c_size_t, P(C.c_size_t)]),
     "et_graph_build": (i32, [u32, vp, u64, vp, vp, vp, vp, P(EtBuildOpts), P(vp)]),
+    "et_plan_build": (i32, [u32, vp, u64, vp, vp, vp, vp, P(EtBuildOpts), P(vp)]),
+    "et_plan_free": (None, [vp]),
+    "et_plan_info_get": (i32, [vp, P(EtGraphInfo)]),
+    "et_plan_arrays_get": (i32, [vp, P(EtPlanArrays)]),
+    "et_graph_from_plan": (i32, [vp, P(EtBuildOpts), P(vp)]),
     "et_graph_free": (None, [vp]),
     "et_graph_info_get": (i32, [vp, P(EtGraphInfo)]),
     "et_graph_converge_fr": (i32, [vp, u32, u64, u64, vp]),

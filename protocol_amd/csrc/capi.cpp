@@ -53,8 +53,24 @@ int et_device_count(void) {
     return n;
 }
 
-int et_graph_build(uint32_t n, const uint8_t* member, uint64_t n_edges, const uint32_t* from, const uint32_t* to,
-                   const uint32_t* value_u32, const et_fr* value_fr, const et_build_opts* opts, et_graph** out) {
+struct et_plan {
+    HostGraph h;
+};
+
+static void read_opts(const et_build_opts* opts, BuildOpts& bo, int& variants, int& device) {
+    variants = 0;
+    device = -1;
+    if (!opts) return;
+    if (opts->n_seg) bo.n_seg = opts->n_seg;
+    bo.seg = opts->seg;
+    if (opts->long_row) bo.long_row = opts->long_row;
+    if (opts->target_blocks) bo.target_blocks = opts->target_blocks;
+    variants = (int)opts->variants;
+    device = opts->device;
+}
+
+int et_plan_build(uint32_t n, const uint8_t* member, uint64_t n_edges, const uint32_t* from, const uint32_t* to,
+                  const uint32_t* value_u32, const et_fr* value_fr, const et_build_opts* opts, et_plan** out) {
     if (!out) return ET_E_INVALID_ARG;
     BuildInput in;
     in.n = n;
@@ -67,24 +83,66 @@ int et_graph_build(uint32_t n, const uint8_t* member, uint64_t n_edges, const ui
     static const uint32_t dummy32 = 0;
     if (n_edges == 0 && !value_u32 && !value_fr) in.val_u32 = &dummy32;
     BuildOpts bo;
-    int variants = 0, device = -1;
-    if (opts) {
-        if (opts->n_seg) bo.n_seg = opts->n_seg;
-        bo.seg = opts->seg;
-        if (opts->long_row) bo.long_row = opts->long_row;
-        if (opts->target_blocks) bo.target_blocks = opts->target_blocks;
-        variants = (int)opts->variants;
-        device = opts->device;
-    }
-    HostGraph h;
+    int variants, device;
+    read_opts(opts, bo, variants, device);
+    std::unique_ptr<et_plan> p(new et_plan());
     std::string err;
-    int rc = build_graph(in, bo, h, err);
+    int rc = build_graph(in, bo, p->h, err);
     if (rc) { set_error(err); return rc; }
+    *out = p.release();
+    return ET_OK;
+}
+void et_plan_free(et_plan* p) { delete p; }
+
+static void fill_info(const HostGraph& h, et_graph_info* info) {
+    std::memset(info, 0, sizeof(*info));
+    info->n = h.n; info->n_valid = h.n_valid; info->n_dangling = h.geo.n_dangling;
+    info->n_seg = h.geo.n_seg; info->seg = h.geo.seg;
+    info->nnz = h.nnz; info->nnz_local = h.nnz_local; info->padded_local = h.n_steps * 64;
+    info->n_slices = (uint32_t)h.slices.size(); info->n_blocks = (uint32_t)h.blocks.size();
+    info->rows_cap = h.geo.rows_cap; info->nd_cap = h.geo.nd_cap;
+    info->vec_len = (uint64_t)h.geo.n_seg * h.geo.seg_stride();
+}
+int et_plan_info_get(const et_plan* p, et_graph_info* info) {
+    if (!p || !info) return ET_E_INVALID_ARG;
+    fill_info(p->h, info);
+    return ET_OK;
+}
+int et_plan_arrays_get(const et_plan* p, et_plan_arrays* out) {
+    if (!p || !out) return ET_E_INVALID_ARG;
+    const HostGraph& h = p->h;
+    static_assert(sizeof(et_slice_desc) == sizeof(SliceDesc) && sizeof(et_block_desc) == sizeof(BlockDesc), "layout");
+    out->pos_of_slot = h.pos_of_ext.data();
+    out->slices = reinterpret_cast<const et_slice_desc*>(h.slices.data());
+    out->blocks = reinterpret_cast<const et_block_desc*>(h.blocks.data());
+    out->col = h.col.data();
+    out->value_u32 = h.values_are_u32 ? h.val_u32.data() : nullptr;
+    out->value_fr = h.values_are_u32 ? nullptr : reinterpret_cast<const et_fr*>(h.val_fr.data());
+    out->scale_fr = reinterpret_cast<const et_fr*>(h.scale_fr.data());
+    out->scale_f64 = h.scale_f64.data();
+    std::memcpy(out->inv_nm1_w.b, h.inv_nm1_w.l, 32);
+    out->n_active = h.geo.n_active; out->n_active_pad = h.geo.n_active_pad;
+    out->n_dangling_pad = h.geo.n_dangling_pad; out->n_dangling_local = h.n_dangling_local;
+    return ET_OK;
+}
+int et_graph_from_plan(const et_plan* p, const et_build_opts* opts, et_graph** out) {
+    if (!p || !out) return ET_E_INVALID_ARG;
     DeviceGraph* dg = nullptr;
-    rc = DeviceGraph::create(h, variants, device, &dg);
+    int rc = DeviceGraph::create(p->h, opts ? (int)opts->variants : 0, opts ? opts->device : -1, &dg);
     if (rc) return rc;
     *out = reinterpret_cast<et_graph*>(dg);
     return ET_OK;
+}
+
+int et_graph_build(uint32_t n, const uint8_t* member, uint64_t n_edges, const uint32_t* from, const uint32_t* to,
+                   const uint32_t* value_u32, const et_fr* value_fr, const et_build_opts* opts, et_graph** out) {
+    if (!out) return ET_E_INVALID_ARG;
+    et_plan* p = nullptr;
+    int rc = et_plan_build(n, member, n_edges, from, to, value_u32, value_fr, opts, &p);
+    if (rc) return rc;
+    rc = et_graph_from_plan(p, opts, out);
+    et_plan_free(p);
+    return rc;
 }
 
 void et_graph_free(et_graph* g) { delete G(g); }

@@ -148,3 +148,51 @@ class Graph:
 
     def unpermute_f64(self, x_ptr, out_ptr, stream=None):
         check(lib().et_graph_unpermute_f64_async(self._h, x_ptr, out_ptr, stream))
+
+
+class Plan:
+    """Host-side layout of an attestation list (et_plan_*): what Graph uploads, without a GPU.
+    Arrays are copied into numpy so they outlive the native object."""
+
+    def __init__(self, n, frm, to, value_u32=None, value_fr=None, member=None, n_seg=1, seg=0,
+                 long_row=0, target_blocks=0):
+        frm = np.ascontiguousarray(frm, dtype=np.uint32)
+        to = np.ascontiguousarray(to, dtype=np.uint32)
+        if value_u32 is not None:
+            value_u32 = np.ascontiguousarray(value_u32, dtype=np.uint32)
+        if value_fr is not None:
+            value_fr = np.ascontiguousarray(value_fr, dtype=np.uint8)
+        if member is not None:
+            member = np.ascontiguousarray(member, dtype=np.uint8)
+        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_blocks, 0, -1)
+        h = C.c_void_p()
+        check(lib().et_plan_build(n, _ptr(member), len(frm), _ptr(frm), _ptr(to), _ptr(value_u32),
+                                  _ptr(value_fr), C.byref(opts), C.byref(h)))
+        try:
+            info = _ffi.EtGraphInfo()
+            check(lib().et_plan_info_get(h, C.byref(info)))
+            arr = _ffi.EtPlanArrays()
+            check(lib().et_plan_arrays_get(h, C.byref(arr)))
+            self.info = info
+            self.n = n
+            slots = int(info.padded_local)
+            vec_len = int(info.vec_len)
+            self.pos_of_slot = np.ctypeslib.as_array(arr.pos_of_slot, (n,)).copy()
+            self.slices = [(s.off, s.len, s.row0, s.nrows) for s in arr.slices[:info.n_slices]]
+            self.blocks = [(b.slice_begin, b.slice_end, b.flags, b.dslot) for b in arr.blocks[:info.n_blocks]]
+            self.col = np.ctypeslib.as_array(arr.col, (slots,)).copy() if slots else np.zeros(0, np.uint32)
+            if arr.value_u32:
+                self.value_u32 = np.ctypeslib.as_array(arr.value_u32, (slots,)).copy() if slots else np.zeros(0, np.uint32)
+                self.value_fr = None
+            else:
+                self.value_u32 = None
+                raw = C.string_at(arr.value_fr, slots * 32) if slots else b""
+                self.value_fr = [int.from_bytes(raw[i:i + 32], "little") for i in range(0, len(raw), 32)]
+            raw = C.string_at(arr.scale_fr, vec_len * 32)
+            self.scale_fr = [int.from_bytes(raw[i:i + 32], "little") for i in range(0, len(raw), 32)]
+            self.scale_f64 = np.ctypeslib.as_array(arr.scale_f64, (vec_len,)).copy()
+            self.inv_nm1_w = int.from_bytes(bytes(arr.inv_nm1_w.b), "little")
+            self.n_active, self.n_active_pad = arr.n_active, arr.n_active_pad
+            self.n_dangling_pad, self.n_dangling_local = arr.n_dangling_pad, arr.n_dangling_local
+        finally:
+            lib().et_plan_free(h)

@@ -1,0 +1,62 @@
+"""Row-sharded converge with the real HIP kernels: two ranks (both on cuda:0) exchanging segments
+through torch.distributed.  gloo stands in for RCCL here because two ranks of one communicator cannot
+share a GPU under RCCL; the kernels, buffers and the protocol are the ones bench.py uses with nccl."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for pth in (ROOT, os.path.join(ROOT, "oracle"), HERE):
+    if pth not in sys.path:
+        sys.path.insert(0, pth)
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, case, ret):
+    import torch
+    import torch.distributed as dist
+    import protocol_amd as pa
+    from protocol_amd.sharded import ShardedGraph
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, member, frm, to, val, iters = case
+    sg = ShardedGraph(n, frm, to, value_u32=val, member=member, device=torch.device("cuda", 0))
+    fr = sg.converge_fr(iters, 1000)          # raises on a conservation failure
+    f64 = sg.converge_f64(iters, 1000.0)
+    if rank == 0:
+        ret["fr"] = fr.tobytes()
+        ret["f64"] = f64.tolist()
+        ret["nnz"] = sg.nnz
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_converge_matches_oracle(world):
+    import c_oracle
+    import protocol_amd as pa
+    n = 50000
+    frm, to, val = pa.synth_graph(3, n, 16 * n, seed=5, value_max=255)
+    member = np.ones(n, dtype=np.uint8)
+    member[::97] = 0
+    iters = 20
+    rc, exp, nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000)
+    assert rc == 0
+    rc, _e64, eld, _r, _n, _s = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=iters,
+                                                             initial=1000.0, want_ld=True)
+    assert rc == 0
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() + world) % 2000
+    mp.spawn(_worker, args=(world, port, (n, member, frm, to, val, iters), ret), nprocs=world, join=True)
+    assert ret["nnz"] == nnz
+    assert ret["fr"] == exp.tobytes()
+    got = np.array(ret["f64"], dtype=np.longdouble)
+    assert float(np.abs(got - eld).sum() / np.abs(eld).sum()) <= 1e-9

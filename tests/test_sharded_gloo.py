@@ -1,0 +1,93 @@
+"""The multi-GPU exchange protocol on CPU: world_size 2, gloo.
+
+Each rank plans its own segment of the graph (protocol_amd.Plan, host only), executes its rows with
+the plan emulator (exact integers / doubles) and exchanges segments with one all-gather per
+iteration, exactly as protocol_amd.sharded.ShardedGraph does with the HIP kernels and RCCL.
+The result must equal the CPU checker's, bit for bit in the field and to 1e-12 in f64.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for pth in (ROOT, os.path.join(ROOT, "oracle"), HERE):
+    if pth not in sys.path:
+        sys.path.insert(0, pth)
+
+LIMB = (1 << 62) - 1   # field elements travel as 5 x 62-bit limbs in int64 tensors
+
+
+def _to_limbs(vals):
+    return torch.tensor([[(v >> (62 * i)) & LIMB for i in range(5)] for v in vals], dtype=torch.int64)
+
+
+def _from_limbs(t):
+    return [sum(int(x) << (62 * i) for i, x in enumerate(row)) for row in t.tolist()]
+
+
+def _worker(rank, world, port, case, ret):
+    import c_oracle  # noqa: F401  (path check)
+    import protocol_amd as pa
+    from plan_emulator import SegmentEmulator
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, member, frm, to, val, iters = case
+    em = SegmentEmulator(pa.Plan(n, frm, to, value_u32=val, member=member, n_seg=world, seg=rank,
+                                 long_row=16, target_blocks=6))
+    seg = em.segment_slice()
+
+    def all_gather(x, field):
+        mine = _to_limbs(x[seg]) if field else torch.tensor(x[seg], dtype=torch.float64)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        for r, p in enumerate(parts):
+            vals = _from_limbs(p) if field else p.numpy()
+            x[r * em.stride:(r + 1) * em.stride] = vals
+
+    out = {}
+    for field in (True, False):
+        x = em.init(1000 if field else 1000.0, field)
+        all_gather(x, field)
+        for _ in range(iters):
+            y = [0] * len(x) if field else np.zeros(len(x))
+            em.step(x, y, field)
+            all_gather(y, field)
+            x = y
+        out["fr" if field else "f64"] = em.unpermute(x, field)
+    if rank == 0:
+        ret["fr"] = out["fr"]
+        ret["f64"] = list(out["f64"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchange_matches_oracle():
+    import c_oracle
+    rng = np.random.default_rng(12)
+    n = 300
+    member = (rng.random(n) > 0.05).astype(np.uint8)
+    deg = rng.poisson(5, n)
+    deg[rng.random(n) < 0.1] = 0
+    frm = np.repeat(np.arange(n, dtype=np.uint32), deg)
+    to = rng.integers(0, n, len(frm), dtype=np.uint32)
+    sel = rng.random(len(frm)) < 0.25
+    to[sel] = rng.integers(0, 2, sel.sum())
+    val = rng.integers(0, 256, len(frm), dtype=np.uint32)
+    iters = 3
+    rc, exp, _nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000)
+    assert rc == 0
+    rc, e64, _ld, _r, _n, _s = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000.0)
+    assert rc == 0
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, (n, member, frm, to, val, iters), ret), nprocs=2, join=True)
+    assert ret["fr"] == c_oracle.fr_bytes_to_ints(exp)
+    got = np.array(ret["f64"])
+    assert np.abs(got - e64).sum() / np.abs(e64).sum() <= 1e-12
