@@ -121,7 +121,7 @@ typedef struct {
     uint32_t n_seg;         /* GPUs sharing the rows of this graph (1 = whole graph here)        */
     uint32_t seg;           /* which share this et_graph holds                                   */
     uint32_t long_row;      /* 0 = default; in-degree above which a row gets a whole wavefront   */
-    uint32_t target_blocks; /* 0 = default; workgroups per iteration launch                      */
+    uint32_t target_work; /* 0 = default; wavefront work items per launch                      */
     uint32_t variants;      /* ET_VARIANT_* bit mask; 0 = both                                   */
     int32_t device;         /* HIP device ordinal; -1 = current device                           */
 } et_build_opts;
@@ -134,7 +134,7 @@ typedef struct {
     uint64_t nnz;           /* surviving attestations of non-dangling members (all shares)       */
     uint64_t nnz_local;     /* ... whose rated peer belongs to this share                        */
     uint64_t padded_local;  /* edge-stream entries incl. padding in this share                   */
-    uint32_t n_slices, n_blocks;
+    uint32_t n_slices, n_work;
     uint32_t rows_cap, nd_cap; /* position-space geometry: segment = rows_cap + nd_cap entries   */
     uint64_t vec_len;       /* entries of one trust vector in position order (all segments)      */
     uint64_t device_bytes;  /* device memory held by this graph                                  */
@@ -154,12 +154,12 @@ int et_graph_info_get(const et_graph *g, et_graph_info *info);
  * split over segments.  Arrays stay owned by the plan. */
 typedef struct et_plan et_plan;
 typedef struct { uint32_t off, len, row0, nrows; } et_slice_desc;   /* nrows bit 31: wavefront-reduced row */
-typedef struct { uint32_t slice_begin, slice_end, flags, dslot; } et_block_desc; /* flags bit 0: dangling rows */
+typedef struct { uint32_t slice_begin, slice_end, flags, dslot; } et_work_desc;  /* one wavefront; flags bit 0: dangling rows */
 typedef struct {
     const uint32_t *pos_of_slot;      /* n: position of each slot's peer, 0xFFFFFFFF for empty slots  */
     const et_slice_desc *slices;      /* n_slices                                                      */
-    const et_block_desc *blocks;      /* n_blocks                                                      */
-    const uint32_t *col;              /* padded_local source positions (step-major, 64 lanes a step)   */
+    const et_work_desc *work;        /* n_work                                                      */
+    const uint32_t *col;              /* padded_local sources, (segment << 29) | local row; step-major */
     const uint32_t *value_u32;        /* padded_local raw opinions, or NULL                            */
     const et_fr *value_fr;            /* padded_local raw opinions, or NULL                            */
     const et_fr *scale_fr;            /* vec_len: inv(row sum) * 2^576 mod r per source position       */

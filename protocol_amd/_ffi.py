@@ -33,14 +33,14 @@ class EtFr(C.Structure):
 
 class EtBuildOpts(C.Structure):
     _fields_ = [("n_seg", C.c_uint32), ("seg", C.c_uint32), ("long_row", C.c_uint32),
-                ("target_blocks", C.c_uint32), ("variants", C.c_uint32), ("device", C.c_int32)]
+                ("target_work", C.c_uint32), ("variants", C.c_uint32), ("device", C.c_int32)]
 
 
 class EtGraphInfo(C.Structure):
     _fields_ = [("n", C.c_uint32), ("n_valid", C.c_uint32), ("n_dangling", C.c_uint32),
                 ("n_seg", C.c_uint32), ("seg", C.c_uint32),
                 ("nnz", C.c_uint64), ("nnz_local", C.c_uint64), ("padded_local", C.c_uint64),
-                ("n_slices", C.c_uint32), ("n_blocks", C.c_uint32),
+                ("n_slices", C.c_uint32), ("n_work", C.c_uint32),
                 ("rows_cap", C.c_uint32), ("nd_cap", C.c_uint32),
                 ("vec_len", C.c_uint64), ("device_bytes", C.c_uint64)]
 
@@ -49,13 +49,13 @@ class EtSliceDesc(C.Structure):
     _fields_ = [("off", C.c_uint32), ("len", C.c_uint32), ("row0", C.c_uint32), ("nrows", C.c_uint32)]
 
 
-class EtBlockDesc(C.Structure):
+class EtWorkDesc(C.Structure):
     _fields_ = [("slice_begin", C.c_uint32), ("slice_end", C.c_uint32), ("flags", C.c_uint32), ("dslot", C.c_uint32)]
 
 
 class EtPlanArrays(C.Structure):
     _fields_ = [("pos_of_slot", C.POINTER(C.c_uint32)), ("slices", C.POINTER(EtSliceDesc)),
-                ("blocks", C.POINTER(EtBlockDesc)), ("col", C.POINTER(C.c_uint32)),
+                ("work", C.POINTER(EtWorkDesc)), ("col", C.POINTER(C.c_uint32)),
                 ("value_u32", C.POINTER(C.c_uint32)), ("value_fr", C.POINTER(EtFr)),
                 ("scale_fr", C.POINTER(EtFr)), ("scale_f64", C.POINTER(C.c_double)),
                 ("inv_nm1_w", EtFr), ("n_active", C.c_uint32), ("n_active_pad", C.c_uint32),

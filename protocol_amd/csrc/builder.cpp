@@ -122,7 +122,10 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         }
     }
     g.nnz = nnz;
-    // ---- 5. global row order: active peers by in-degree (desc), then dangling peers ----------
+    // ---- 5. global row order ------------------------------------------------------------------
+    // Active peers: the opt.hot_fr most-gathered (highest out-degree), then the next most-gathered up
+    // to opt.hot_f64, then the rest; inside each group by in-degree (descending) so that the 64 rows
+    // of a slice have similar lengths.  Dangling peers follow.
     const uint32_t n_active = n_valid - n_dangling;
     std::vector<uint32_t> order;
     order.reserve(n_valid);
@@ -133,7 +136,20 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         if (out_deg[a] != out_deg[b]) return out_deg[a] > out_deg[b];
         return a < b;
     };
-    std::sort(order.begin(), order.begin() + n_active, by_deg);
+    auto by_out = [&](uint32_t a, uint32_t b) {
+        if (out_deg[a] != out_deg[b]) return out_deg[a] > out_deg[b];
+        return a < b;
+    };
+    {
+        const uint32_t h1 = std::min<uint32_t>(n_active, std::max(opt.hot_f64, opt.hot_fr));
+        const uint32_t h0 = std::min<uint32_t>(h1, std::min(opt.hot_f64, opt.hot_fr));
+        auto b = order.begin();
+        if (h1 < n_active) std::nth_element(b, b + h1, b + n_active, by_out);
+        if (h0 < h1) std::nth_element(b, b + h0, b + h1, by_out);
+        std::sort(b, b + h0, by_deg);
+        std::sort(b + h0, b + h1, by_deg);
+        std::sort(b + h1, b + n_active, by_deg);
+    }
     std::sort(order.begin() + n_active, order.end(), by_deg);
 
     const uint32_t G = opt.n_seg;
@@ -145,10 +161,18 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     geo.n_dangling = n_dangling;
     geo.n_dangling_pad = round_up(n_dangling, 64 * G);
     geo.rows_cap = (geo.n_active_pad + geo.n_dangling_pad) / G;
-    geo.nd_cap = opt.nd_cap ? opt.nd_cap : 32;
+    // one partial-sum slot per wavefront that owns dangling rows; the count depends only on global
+    // quantities so that every segment derives the same geometry
+    const uint32_t target_work = opt.target_work ? opt.target_work : 16384;
+    {
+        uint64_t share = ((uint64_t)target_work * n_dangling + n_valid - 1) / n_valid;
+        geo.nd_cap = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(16, (share + 15) / 16 * 16));
+    }
+    geo.hot_f64 = std::min<uint32_t>(geo.rows_cap, (opt.hot_f64 / G) / 64 * 64);
+    geo.hot_fr = std::min<uint32_t>(geo.rows_cap, (opt.hot_fr / G) / 64 * 64);
     g.geo = geo;
-    if ((uint64_t)G * geo.seg_stride() >= 0xFFFFFFFFull) {
-        err = "position space exceeds 32 bits";
+    if (G > 8 || geo.seg_stride() >= COL_LOCAL_MASK) {
+        err = "more than 8 segments or more than 2^29 rows per segment";
         return ET_E_UNSUPPORTED;
     }
     Pos P{G, geo.seg_stride()};
@@ -197,7 +221,7 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     }
     for (uint32_t i = 0; i < geo.rows_cap; ++i) in_ptr[i + 1] += in_ptr[i];
     g.nnz_local = in_ptr[geo.rows_cap];
-    std::vector<uint32_t> e_src(g.nnz_local);   // source position
+    std::vector<uint32_t> e_src(g.nnz_local);   // source, encoded (segment << 29) | local row
     std::vector<uint64_t> e_idx(g.nnz_local);   // original edge index (for the value)
     {
         // visit attesters in ascending POSITION so that every row's sources come out sorted
@@ -206,6 +230,7 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         std::sort(by_pos.begin(), by_pos.end(), [&](uint32_t a, uint32_t b) { return g.pos_of_ext[a] < g.pos_of_ext[b]; });
         for (uint32_t f : by_pos) {
             uint32_t pf = g.pos_of_ext[f];
+            pf = ((pf / geo.seg_stride()) << COL_SEG_SHIFT) | (pf % geo.seg_stride());
             for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
                 if (drop[k]) continue;
                 uint32_t lr = local_row(in.to[kept[k]]);
@@ -282,34 +307,35 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
             }
         }
     }
-    // ---- 10. workgroups: contiguous, class-pure, equal estimated cost ---------------------------
+    // ---- 10. wavefront work items: contiguous, class-pure, equal estimated cost ------------------
     const uint32_t n_slices = (uint32_t)g.slices.size();
     uint32_t first_dang = n_slices;
     for (uint32_t s = 0; s < n_slices; ++s) if (slice_dangling[s]) { first_dang = s; break; }
     auto cost = [&](uint32_t s) -> uint64_t { return (uint64_t)g.slices[s].len + 6; };
-    auto partition = [&](uint32_t sb, uint32_t se, uint32_t max_blocks, bool dang) {
+    uint64_t cost_a = 0, cost_d = 0;
+    for (uint32_t s = 0; s < first_dang; ++s) cost_a += cost(s);
+    for (uint32_t s = first_dang; s < n_slices; ++s) cost_d += cost(s);
+    auto partition = [&](uint32_t sb, uint32_t se, uint32_t max_items, bool dang) {
         if (sb >= se) return;
         uint64_t total = 0;
         for (uint32_t s = sb; s < se; ++s) total += cost(s);
-        uint32_t nb = std::max<uint32_t>(1, std::min<uint32_t>(max_blocks, (se - sb + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+        uint32_t nb = std::max<uint32_t>(1, std::min<uint32_t>(max_items, se - sb));
         uint64_t per = (total + nb - 1) / nb;
         uint32_t s = sb, dslot = 0;
         while (s < se) {
             uint64_t acc = 0;
             uint32_t b = s;
-            while (s < se && (acc < per || s - b < 1)) acc += cost(s++);
-            // never leave more blocks than allowed: the last block takes the rest
-            if ((uint32_t)g.blocks.size() + 1 >= 0xFFFFFFF0u) break;
-            BlockDesc bd{b, s, dang ? BLOCK_DANGLING : 0u, dang ? dslot++ : 0u};
-            g.blocks.push_back(bd);
+            while (s < se && (acc < per || s == b)) acc += cost(s++);
+            g.work.push_back(WorkDesc{b, s, dang ? WORK_DANGLING : 0u, dang ? dslot++ : 0u});
         }
     };
-    const uint32_t target = opt.target_blocks ? opt.target_blocks : 2048;
-    partition(0, first_dang, target, false);
-    size_t nb_active = g.blocks.size();
-    partition(first_dang, n_slices, geo.nd_cap, true);
-    if (g.blocks.size() - nb_active > geo.nd_cap) {
-        err = "internal: more dangling workgroups than partial-sum slots";
+    uint32_t items_d = 0;
+    if (cost_d) items_d = (uint32_t)std::min<uint64_t>(geo.nd_cap, std::max<uint64_t>(1, target_work * cost_d / (cost_a + cost_d)));
+    partition(0, first_dang, std::max<uint32_t>(1, target_work - items_d), false);
+    size_t n_active_items = g.work.size();
+    partition(first_dang, n_slices, items_d, true);
+    if (g.work.size() - n_active_items > geo.nd_cap) {
+        err = "internal: more dangling work items than partial-sum slots";
         return ET_E_UNSUPPORTED;
     }
     return ET_OK;

@@ -34,8 +34,9 @@ struct BuildOpts {
     uint32_t n_seg = 1;          // GPUs sharing the rows
     uint32_t seg = 0;            // this GPU
     uint32_t long_row = 128;     // in-degree above which a row is spread over a whole wavefront
-    uint32_t target_blocks = 2048;
-    uint32_t nd_cap = 32;        // partial-sum slots per segment (>= workgroups holding dangling rows)
+    uint32_t target_work = 16384; // wavefront work items per iteration launch (several rounds of 256 CUs x 16 waves)
+    uint32_t hot_f64 = 16384;    // LDS-resident sources, f64 variant (128 KiB of doubles)
+    uint32_t hot_fr = 0;         // LDS-resident sources, Fr variant (0 = off: measured no gain, the misses are cold sources)
 };
 
 struct HostGraph {
@@ -47,9 +48,9 @@ struct HostGraph {
     Geometry geo{};
     std::vector<uint32_t> pos_of_ext;   // n entries: position of each peer, 0xFFFFFFFF for empty slots
     std::vector<SliceDesc> slices;
-    std::vector<BlockDesc> blocks;
+    std::vector<WorkDesc> work;
     uint64_t n_steps = 0;
-    std::vector<uint32_t> col;          // n_steps*64 source positions
+    std::vector<uint32_t> col;          // n_steps*64 sources, (segment << 29) | local row
     std::vector<uint32_t> val_u32;      // n_steps*64 raw opinions (values_are_u32)
     std::vector<FrRaw> val_fr;          // n_steps*64 raw opinions (!values_are_u32)
     // Per-position source factors (zero for dangling / non-member / padding positions):

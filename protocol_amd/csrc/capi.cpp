@@ -1,4 +1,5 @@
 // extern "C" surface of the graph engine (declarations and contracts: include/eigentrust_hip.h).
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -64,9 +65,17 @@ static void read_opts(const et_build_opts* opts, BuildOpts& bo, int& variants, i
     if (opts->n_seg) bo.n_seg = opts->n_seg;
     bo.seg = opts->seg;
     if (opts->long_row) bo.long_row = opts->long_row;
-    if (opts->target_blocks) bo.target_blocks = opts->target_blocks;
+    if (opts->target_work) bo.target_work = opts->target_work;
     variants = (int)opts->variants;
     device = opts->device;
+}
+
+// Tuning knobs for experiments (not part of the ABI): ET_TARGET_WORK, ET_HOT_F64, ET_HOT_FR, ET_LONG_ROW.
+static void read_env(BuildOpts& bo) {
+    if (const char* e = getenv("ET_TARGET_WORK")) bo.target_work = (uint32_t)atoi(e);
+    if (const char* e = getenv("ET_HOT_F64")) bo.hot_f64 = (uint32_t)atoi(e);
+    if (const char* e = getenv("ET_HOT_FR")) bo.hot_fr = (uint32_t)atoi(e);
+    if (const char* e = getenv("ET_LONG_ROW")) bo.long_row = (uint32_t)atoi(e);
 }
 
 int et_plan_build(uint32_t n, const uint8_t* member, uint64_t n_edges, const uint32_t* from, const uint32_t* to,
@@ -85,6 +94,7 @@ int et_plan_build(uint32_t n, const uint8_t* member, uint64_t n_edges, const uin
     BuildOpts bo;
     int variants, device;
     read_opts(opts, bo, variants, device);
+    read_env(bo);
     std::unique_ptr<et_plan> p(new et_plan());
     std::string err;
     int rc = build_graph(in, bo, p->h, err);
@@ -99,7 +109,7 @@ static void fill_info(const HostGraph& h, et_graph_info* info) {
     info->n = h.n; info->n_valid = h.n_valid; info->n_dangling = h.geo.n_dangling;
     info->n_seg = h.geo.n_seg; info->seg = h.geo.seg;
     info->nnz = h.nnz; info->nnz_local = h.nnz_local; info->padded_local = h.n_steps * 64;
-    info->n_slices = (uint32_t)h.slices.size(); info->n_blocks = (uint32_t)h.blocks.size();
+    info->n_slices = (uint32_t)h.slices.size(); info->n_work = (uint32_t)h.work.size();
     info->rows_cap = h.geo.rows_cap; info->nd_cap = h.geo.nd_cap;
     info->vec_len = (uint64_t)h.geo.n_seg * h.geo.seg_stride();
 }
@@ -111,10 +121,10 @@ int et_plan_info_get(const et_plan* p, et_graph_info* info) {
 int et_plan_arrays_get(const et_plan* p, et_plan_arrays* out) {
     if (!p || !out) return ET_E_INVALID_ARG;
     const HostGraph& h = p->h;
-    static_assert(sizeof(et_slice_desc) == sizeof(SliceDesc) && sizeof(et_block_desc) == sizeof(BlockDesc), "layout");
+    static_assert(sizeof(et_slice_desc) == sizeof(SliceDesc) && sizeof(et_work_desc) == sizeof(WorkDesc), "layout");
     out->pos_of_slot = h.pos_of_ext.data();
     out->slices = reinterpret_cast<const et_slice_desc*>(h.slices.data());
-    out->blocks = reinterpret_cast<const et_block_desc*>(h.blocks.data());
+    out->work = reinterpret_cast<const et_work_desc*>(h.work.data());
     out->col = h.col.data();
     out->value_u32 = h.values_are_u32 ? h.val_u32.data() : nullptr;
     out->value_fr = h.values_are_u32 ? nullptr : reinterpret_cast<const et_fr*>(h.val_fr.data());
@@ -154,7 +164,7 @@ int et_graph_info_get(const et_graph* g, et_graph_info* info) {
     info->n = d->n; info->n_valid = d->n_valid; info->n_dangling = d->geo.n_dangling;
     info->n_seg = d->geo.n_seg; info->seg = d->geo.seg;
     info->nnz = d->nnz; info->nnz_local = d->nnz_local; info->padded_local = d->n_steps * 64;
-    info->n_slices = d->n_slices; info->n_blocks = d->n_blocks;
+    info->n_slices = d->n_slices; info->n_work = d->n_work;
     info->rows_cap = d->geo.rows_cap; info->nd_cap = d->geo.nd_cap;
     info->vec_len = d->vec_len; info->device_bytes = d->device_bytes;
     return ET_OK;

@@ -42,26 +42,26 @@ static const uint32_t STATS_RING = 64;
 // kernels: normalisation (native.rs:305-314, once per graph)
 // ---------------------------------------------------------------------------------------------
 __global__ void k_normalise_f64_u32(const uint32_t* __restrict__ col, const uint32_t* __restrict__ val,
-                                    const double* __restrict__ scale, double* __restrict__ w, size_t slots) {
+                                    const double* __restrict__ scale, double* __restrict__ w, size_t slots, Geometry g) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < slots) w[i] = (double)val[i] * scale[col[i]];
+    if (i < slots) w[i] = (double)val[i] * scale[g.pos_of_col(col[i])];
 }
 __global__ void k_normalise_f64_fr(const uint32_t* __restrict__ col, const uint4* __restrict__ val,
-                                   const double* __restrict__ scale, double* __restrict__ w, size_t slots) {
+                                   const double* __restrict__ scale, double* __restrict__ w, size_t slots, Geometry g) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= slots) return;
     U256 v = u256_load(val + 2 * i);
     double d = 0.0;
 #pragma unroll
     for (int k = 7; k >= 0; --k) d = d * 4294967296.0 + (double)v.v[k];
-    w[i] = d * scale[col[i]];
+    w[i] = d * scale[g.pos_of_col(col[i])];
 }
 __global__ void k_normalise_fr_u32(const uint32_t* __restrict__ col, const uint32_t* __restrict__ val,
                                    const uint4* __restrict__ scale, uint4* __restrict__ wlo,
-                                   uint4* __restrict__ whi, size_t slots) {
+                                   uint4* __restrict__ whi, size_t slots, Geometry g) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= slots) return;
-    U256 k = u256_load(scale + 2 * (size_t)col[i]);
+    U256 k = u256_load(scale + 2 * (size_t)g.pos_of_col(col[i]));
     Acc a = acc_zero();
     acc_mac_u32(a, k, val[i]);
     U256 w = acc_redc288(a);  // v * inv(sum) * 2^576 * 2^-288 = weight * 2^288
@@ -70,10 +70,10 @@ __global__ void k_normalise_fr_u32(const uint32_t* __restrict__ col, const uint3
 }
 __global__ void k_normalise_fr_fr(const uint32_t* __restrict__ col, const uint4* __restrict__ val,
                                   const uint4* __restrict__ scale, uint4* __restrict__ wlo,
-                                  uint4* __restrict__ whi, size_t slots) {
+                                  uint4* __restrict__ whi, size_t slots, Geometry g) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= slots) return;
-    U256 k = u256_load(scale + 2 * (size_t)col[i]);
+    U256 k = u256_load(scale + 2 * (size_t)g.pos_of_col(col[i]));
     U256 v = u256_load(val + 2 * i);
     Acc a = acc_zero();
     acc_mac(a, k, v);
@@ -111,17 +111,21 @@ __global__ void k_init_fr(Geometry g, U256 initial, U256 d0, uint4* __restrict__
 // ---------------------------------------------------------------------------------------------
 // kernels: one iteration
 // ---------------------------------------------------------------------------------------------
+static const int WPB_F64 = 16;  // wavefronts per workgroup: one 1024-thread workgroup per CU
+static const int WPB_FR = 8;    // two 512-thread workgroups per CU (the Fr kernel needs > 128 VGPRs)
+
 struct StepArgsF64 {
-    const BlockDesc* blocks;
+    const WorkDesc* work;
     const SliceDesc* slices;
     const uint32_t* col;
     const double* w;
     const double* x;
     double* y;
     const double* pretrust;  // position order, may be null
-    double* res_part;        // [n_blocks] of this iteration
+    double* res_part;        // [n_work] of this iteration
     double* sum_part;
     Geometry geo;
+    uint32_t n_work;
     double inv_nm1;
     double alpha;
 };
@@ -132,15 +136,20 @@ ET_DEV double wave_sum_f64(double v) {
     return v;
 }
 
+// Workgroup = 16 wavefronts sharing one LDS tile with the first geo.hot_f64 entries of every segment
+// (the most-gathered sources).  Each wavefront owns one work item (a run of slices).
 template <bool HAS_ALPHA>
-__global__ __launch_bounds__(BLOCK_THREADS) void k_step_f64(StepArgsF64 a) {
-    __shared__ double red[3][WAVES_PER_BLOCK];
-    const BlockDesc bd = a.blocks[blockIdx.x];
+__global__ __launch_bounds__(WPB_F64 * 64) void k_step_f64(StepArgsF64 a) {
+    extern __shared__ double tile_f64[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t stride = a.geo.seg_stride();
+    const uint32_t hot = a.geo.hot_f64;
     const size_t my_base = (size_t)a.geo.seg * stride;
-    const bool dang = (bd.flags & BLOCK_DANGLING) != 0;
+    const double* __restrict__ xr = a.x;
+
+    for (uint32_t sg = 0; sg < a.geo.n_seg; ++sg)
+        for (uint32_t t = threadIdx.x; t < hot; t += WPB_F64 * 64) tile_f64[sg * hot + t] = xr[(size_t)sg * stride + t];
 
     // score mass of dangling peers: fixed-order sum of every segment's partial sums
     double D = 0.0;
@@ -148,15 +157,20 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step_f64(StepArgsF64 a) {
         const uint32_t total = a.geo.n_seg * a.geo.nd_cap;
         for (uint32_t t = lane; t < total; t += 64) {
             uint32_t sg = t / a.geo.nd_cap, k = t - sg * a.geo.nd_cap;
-            D += a.x[(size_t)sg * stride + a.geo.rows_cap + k];
+            D += xr[(size_t)sg * stride + a.geo.rows_cap + k];
         }
         D = wave_sum_f64(D);
     }
     const double dterm = D * a.inv_nm1;
+    __syncthreads();
 
-    const double* __restrict__ xr = a.x;
+    const uint32_t gw = blockIdx.x * WPB_F64 + wave;
+    if (gw >= a.n_work) return;
+    const WorkDesc wd = a.work[gw];
+    const bool dang = (wd.flags & WORK_DANGLING) != 0;
+
     double res = 0.0, tot = 0.0, dacc = 0.0;
-    for (uint32_t s = bd.slice_begin + wave; s < bd.slice_end; s += WAVES_PER_BLOCK) {
+    for (uint32_t s = wd.slice_begin; s < wd.slice_end; ++s) {
         const SliceDesc sd = a.slices[s];
         const uint32_t* __restrict__ cp = a.col + (size_t)sd.off * 64 + lane;
         const double* __restrict__ wp = a.w + (size_t)sd.off * 64 + lane;
@@ -184,7 +198,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step_f64(StepArgsF64 a) {
 #pragma unroll
                     for (int i = 0; i < U; ++i) w[i] = wp[(size_t)min(k + i, last) * 64];
 #pragma unroll
-                    for (int i = 0; i < U; ++i) xv[i] = xr[c[i]];
+                    for (int i = 0; i < U; ++i) {
+                        const uint32_t sg = c[i] >> COL_SEG_SHIFT, loc = c[i] & COL_LOCAL_MASK;
+                        if (loc < hot) xv[i] = tile_f64[sg * hot + loc];
+                        else xv[i] = xr[(size_t)sg * stride + loc];
+                    }
                     if (k + U < len) {
 #pragma unroll
                         for (int i = 0; i < U; ++i) c[i] = cp[(size_t)min(k + U + i, last) * 64];
@@ -210,28 +228,25 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step_f64(StepArgsF64 a) {
     res = wave_sum_f64(res);
     tot = wave_sum_f64(tot);
     dacc = wave_sum_f64(dacc);
-    if (lane == 0) { red[0][wave] = res; red[1][wave] = tot; red[2][wave] = dacc; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double r = 0.0, t = 0.0, d = 0.0;
-        for (int w = 0; w < WAVES_PER_BLOCK; ++w) { r += red[0][w]; t += red[1][w]; d += red[2][w]; }
-        a.res_part[blockIdx.x] = r;
-        a.sum_part[blockIdx.x] = t;
-        if (dang) a.y[my_base + a.geo.rows_cap + bd.dslot] = d;
+    if (lane == 0) {
+        a.res_part[gw] = res;
+        a.sum_part[gw] = tot;
+        if (dang) a.y[my_base + a.geo.rows_cap + wd.dslot] = dacc;
     }
 }
 
 struct StepArgsFr {
-    const BlockDesc* blocks;
+    const WorkDesc* work;
     const SliceDesc* slices;
     const uint32_t* col;
     const uint4* wlo;
     const uint4* whi;
     const uint4* x;
     uint4* y;
-    uint4* sum_part;       // [n_blocks][2]
-    uint32_t* chg_part;    // [n_blocks]
+    uint4* sum_part;       // [n_work][2]
+    uint32_t* chg_part;    // [n_work]
     Geometry geo;
+    uint32_t n_work;
     U256 inv_nm1_w;        // inv(n_valid-1) * 2^288 mod r
 };
 
@@ -246,18 +261,18 @@ ET_DEV U256 fr_wave_sum(U256 v) {
     return v;
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS) void k_step_fr(StepArgsFr a) {
+__global__ __launch_bounds__(WPB_FR * 64) void k_step_fr(StepArgsFr a) {
+    extern __shared__ uint4 tile_fr[];                 // 2 x uint4 per hot source
     __shared__ uint32_t sh_d[9];                       // integer sum of the partial sums, plus r (< 2^288)
-    __shared__ uint32_t sh_pd[17];                     // inv_nm1_w * that sum, unreduced
-    __shared__ uint32_t sh_tot[WAVES_PER_BLOCK][8];
-    __shared__ uint32_t sh_dac[WAVES_PER_BLOCK][8];
-    __shared__ uint32_t sh_chg[WAVES_PER_BLOCK];
-    const BlockDesc bd = a.blocks[blockIdx.x];
+    __shared__ uint32_t sh_pd[17];                     // inv_nm1_w * sum of the partial sums, unreduced
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t stride = a.geo.seg_stride();
+    const uint32_t hot = a.geo.hot_fr;
     const size_t my_base = (size_t)a.geo.seg * stride;
-    const bool dang = (bd.flags & BLOCK_DANGLING) != 0;
+
+    for (uint32_t sg = 0; sg < a.geo.n_seg; ++sg)
+        for (uint32_t t = threadIdx.x; t < 2 * hot; t += WPB_FR * 64) tile_fr[2 * sg * hot + t] = a.x[2 * (size_t)sg * stride + t];
 
     if (wave == 0) {
         Acc d = acc_zero();
@@ -300,13 +315,17 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step_fr(StepArgsFr a) {
         }
     }
     __syncthreads();
+    const uint32_t gw = blockIdx.x * WPB_FR + wave;
+    if (gw >= a.n_work) return;
+    const WorkDesc wd = a.work[gw];
+    const bool dang = (wd.flags & WORK_DANGLING) != 0;
     Acc PD;
 #pragma unroll
     for (int i = 0; i < 17; ++i) PD.v[i] = sh_pd[i];
 
     U256 tot = u256_zero(), dacc = u256_zero();
     uint32_t changed = 0;
-    for (uint32_t s = bd.slice_begin + wave; s < bd.slice_end; s += WAVES_PER_BLOCK) {
+    for (uint32_t s = wd.slice_begin; s < wd.slice_end; ++s) {
         const SliceDesc sd = a.slices[s];
         const uint32_t* __restrict__ cp = a.col + (size_t)sd.off * 64 + lane;
         const uint4* __restrict__ lop = a.wlo + (size_t)sd.off * 64 + lane;
@@ -314,9 +333,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step_fr(StepArgsFr a) {
         Acc acc = acc_zero();
 #pragma unroll 2
         for (uint32_t k = 0; k < sd.len; ++k) {
-            uint32_t c = cp[(size_t)k * 64];
+            const uint32_t c = cp[(size_t)k * 64];
             U256 w = u256_from_planes(lop[(size_t)k * 64], hip_[(size_t)k * 64]);
-            U256 xv = u256_load(a.x + 2 * (size_t)c);
+            const uint32_t sg = c >> COL_SEG_SHIFT, loc = c & COL_LOCAL_MASK;
+            U256 xv;
+            if (loc < hot) xv = u256_load(tile_fr + 2 * (sg * hot + loc));
+            else xv = u256_load(a.x + 2 * ((size_t)sg * stride + loc));
             acc_mac(acc, w, xv);
         }
         const bool reduce = (sd.nrows & SLICE_REDUCE) != 0;
@@ -362,25 +384,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step_fr(StepArgsFr a) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) changed += __shfl_xor(changed, off, 64);
     if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { sh_tot[wave][i] = tot.v[i]; sh_dac[wave][i] = dacc.v[i]; }
-        sh_chg[wave] = changed;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        U256 t = u256_zero(), d = u256_zero();
-        uint32_t c = 0;
-        for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
-            U256 tw, dw;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { tw.v[i] = sh_tot[w][i]; dw.v[i] = sh_dac[w][i]; }
-            t = fr_add(t, tw);
-            d = fr_add(d, dw);
-            c += sh_chg[w];
-        }
-        u256_store(a.sum_part + 2 * (size_t)blockIdx.x, t);
-        a.chg_part[blockIdx.x] = c;
-        if (dang) u256_store(a.y + 2 * (my_base + a.geo.rows_cap + bd.dslot), d);
+        u256_store(a.sum_part + 2 * (size_t)gw, tot);
+        a.chg_part[gw] = changed;
+        if (dang) u256_store(a.y + 2 * (my_base + a.geo.rows_cap + wd.dslot), dacc);
     }
 }
 
@@ -388,19 +394,19 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step_fr(StepArgsFr a) {
 // kernels: statistics, un-permutation, self-test
 // ---------------------------------------------------------------------------------------------
 __global__ void k_stats_f64(const double* __restrict__ res_part, const double* __restrict__ sum_part,
-                            uint32_t n_blocks, double* __restrict__ out2) {
+                            uint32_t n_work, double* __restrict__ out2) {
     // one wavefront, fixed order
     double r = 0.0, t = 0.0;
-    for (uint32_t i = threadIdx.x; i < n_blocks; i += 64) { r += res_part[i]; t += sum_part[i]; }
+    for (uint32_t i = threadIdx.x; i < n_work; i += 64) { r += res_part[i]; t += sum_part[i]; }
     r = wave_sum_f64(r);
     t = wave_sum_f64(t);
     if (threadIdx.x == 0) { out2[0] = r; out2[1] = t; }
 }
 __global__ void k_stats_fr(const uint4* __restrict__ sum_part, const uint32_t* __restrict__ chg_part,
-                           uint32_t n_blocks, uint4* __restrict__ out_sum, unsigned long long* __restrict__ out_chg) {
+                           uint32_t n_work, uint4* __restrict__ out_sum, unsigned long long* __restrict__ out_chg) {
     U256 t = u256_zero();
     unsigned long long c = 0;
-    for (uint32_t i = threadIdx.x; i < n_blocks; i += 64) {
+    for (uint32_t i = threadIdx.x; i < n_work; i += 64) {
         t = fr_add(t, u256_load(sum_part + 2 * (size_t)i));
         c += chg_part[i];
     }
@@ -460,7 +466,7 @@ static int dev_upload(T** p, const std::vector<T>& v, uint64_t& total) {
 
 DeviceGraph::~DeviceGraph() {
     if (device >= 0) (void)hipSetDevice(device);
-    void* ptrs[] = {d_blocks, d_slices, d_col, d_w64, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
+    void* ptrs[] = {d_work, d_slices, d_col, d_w64, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
                     d_chg_part, d_stat_out, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* e : ev_begin) (void)hipEventDestroy((hipEvent_t)e);
@@ -484,13 +490,13 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     g->variants = variants_ ? variants_ : (ET_VARIANT_FR | ET_VARIANT_F64);
     g->n = h.n; g->n_valid = h.n_valid; g->nnz = h.nnz; g->nnz_local = h.nnz_local;
     g->geo = h.geo; g->n_steps = h.n_steps; g->n_slices = (uint32_t)h.slices.size();
-    g->n_blocks = (uint32_t)h.blocks.size(); g->n_dangling_local = h.n_dangling_local;
+    g->n_work = (uint32_t)h.work.size(); g->n_dangling_local = h.n_dangling_local;
     g->pos_of_ext = h.pos_of_ext;
     g->inv_nm1_w = h.inv_nm1_w;
     g->inv_nm1 = 1.0 / (double)(h.n_valid - 1);
     uint64_t& tot = g->device_bytes;
     int rc;
-    if ((rc = dev_upload(&g->d_blocks, h.blocks, tot))) return rc;
+    if ((rc = dev_upload(&g->d_work, h.work, tot))) return rc;
     if ((rc = dev_upload(&g->d_slices, h.slices, tot))) return rc;
     if ((rc = dev_upload(&g->d_col, h.col, tot))) return rc;
     if ((rc = dev_upload(&g->d_pos, h.pos_of_ext, tot))) return rc;
@@ -511,32 +517,36 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     if (g->variants & ET_VARIANT_F64) {
         if ((rc = dev_upload(&d_scale64, h.scale_f64, tmp_bytes)) || (rc = dev_alloc(&g->d_w64, slots, tot))) { free_tmp(); return rc; }
         if (slots) {
-            if (h.values_are_u32) hipLaunchKernelGGL(k_normalise_f64_u32, dim3(nb), dim3(256), 0, 0, g->d_col, d_val32, d_scale64, g->d_w64, slots);
-            else hipLaunchKernelGGL(k_normalise_f64_fr, dim3(nb), dim3(256), 0, 0, g->d_col, d_valfr, d_scale64, g->d_w64, slots);
+            if (h.values_are_u32) hipLaunchKernelGGL(k_normalise_f64_u32, dim3(nb), dim3(256), 0, 0, g->d_col, d_val32, d_scale64, g->d_w64, slots, h.geo);
+            else hipLaunchKernelGGL(k_normalise_f64_fr, dim3(nb), dim3(256), 0, 0, g->d_col, d_valfr, d_scale64, g->d_w64, slots, h.geo);
         }
         for (int i = 0; i < 2; ++i) {
             if ((rc = dev_alloc(&g->vx[i], vec_len, tot))) { free_tmp(); return rc; }
             HIP_TRY(hipMemset(g->vx[i], 0, vec_len * sizeof(double)));
         }
-        if ((rc = dev_alloc(&g->out_f64, h.n, tot)) || (rc = dev_alloc(&g->d_res_part, (size_t)STATS_RING * g->n_blocks, tot)) ||
-            (rc = dev_alloc(&g->d_sum_part, (size_t)STATS_RING * g->n_blocks, tot))) { free_tmp(); return rc; }
+        if ((rc = dev_alloc(&g->out_f64, h.n, tot)) || (rc = dev_alloc(&g->d_res_part, (size_t)STATS_RING * g->n_work, tot)) ||
+            (rc = dev_alloc(&g->d_sum_part, (size_t)STATS_RING * g->n_work, tot))) { free_tmp(); return rc; }
     }
     if (g->variants & ET_VARIANT_FR) {
         rc = dev_alloc(&d_scale_fr, vec_len * 2, tmp_bytes);
         if (!rc) HIP_TRY(hipMemcpy(d_scale_fr, h.scale_fr.data(), vec_len * 32, hipMemcpyHostToDevice));
         if (rc || (rc = dev_alloc(&g->d_wlo, slots, tot)) || (rc = dev_alloc(&g->d_whi, slots, tot))) { free_tmp(); return rc; }
         if (slots) {
-            if (h.values_are_u32) hipLaunchKernelGGL(k_normalise_fr_u32, dim3(nb), dim3(256), 0, 0, g->d_col, d_val32, d_scale_fr, g->d_wlo, g->d_whi, slots);
-            else hipLaunchKernelGGL(k_normalise_fr_fr, dim3(nb), dim3(256), 0, 0, g->d_col, d_valfr, d_scale_fr, g->d_wlo, g->d_whi, slots);
+            if (h.values_are_u32) hipLaunchKernelGGL(k_normalise_fr_u32, dim3(nb), dim3(256), 0, 0, g->d_col, d_val32, d_scale_fr, g->d_wlo, g->d_whi, slots, h.geo);
+            else hipLaunchKernelGGL(k_normalise_fr_fr, dim3(nb), dim3(256), 0, 0, g->d_col, d_valfr, d_scale_fr, g->d_wlo, g->d_whi, slots, h.geo);
         }
         for (int i = 0; i < 2; ++i) {
             if ((rc = dev_alloc(&g->fx[i], vec_len * 2, tot))) { free_tmp(); return rc; }
             HIP_TRY(hipMemset(g->fx[i], 0, vec_len * 32));
         }
-        if ((rc = dev_alloc(&g->out_fr, (size_t)h.n * 2, tot)) || (rc = dev_alloc(&g->d_frsum_part, (size_t)STATS_RING * g->n_blocks * 2, tot)) ||
-            (rc = dev_alloc(&g->d_chg_part, (size_t)STATS_RING * g->n_blocks, tot))) { free_tmp(); return rc; }
+        if ((rc = dev_alloc(&g->out_fr, (size_t)h.n * 2, tot)) || (rc = dev_alloc(&g->d_frsum_part, (size_t)STATS_RING * g->n_work * 2, tot)) ||
+            (rc = dev_alloc(&g->d_chg_part, (size_t)STATS_RING * g->n_work, tot))) { free_tmp(); return rc; }
     }
     if ((rc = dev_alloc(&g->d_stat_out, 64, tot))) { free_tmp(); return rc; }
+    // the LDS tiles exceed the 64 KiB a kernel may use without opting in
+    HIP_TRY(hipFuncSetAttribute((const void*)k_step_f64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_step_f64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_step_fr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     free_tmp();
@@ -565,16 +575,18 @@ int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double
     if (!(variants & ET_VARIANT_F64)) { set_error("graph was built without the f64 variant"); return ET_E_UNSUPPORTED; }
     if (x == y) { set_error("step needs distinct input and output vectors"); return ET_E_INVALID_ARG; }
     StepArgsF64 a;
-    a.blocks = d_blocks; a.slices = d_slices; a.col = d_col; a.w = d_w64; a.x = x; a.y = y; a.pretrust = pretrust;
-    size_t ring = (size_t)(iteration % STATS_RING) * n_blocks;
+    a.work = d_work; a.slices = d_slices; a.col = d_col; a.w = d_w64; a.x = x; a.y = y; a.pretrust = pretrust;
+    size_t ring = (size_t)(iteration % STATS_RING) * n_work;
     a.res_part = d_res_part + ring; a.sum_part = d_sum_part + ring;
-    a.geo = geo; a.inv_nm1 = inv_nm1; a.alpha = alpha;
-    if (n_blocks == 0) return ET_OK;
+    a.geo = geo; a.n_work = n_work; a.inv_nm1 = inv_nm1; a.alpha = alpha;
+    if (n_work == 0) return ET_OK;
+    const unsigned grid = (n_work + WPB_F64 - 1) / WPB_F64;
+    const size_t lds = (size_t)geo.n_seg * geo.hot_f64 * sizeof(double);
     if (alpha != 0.0) {
         if (!pretrust) { set_error("alpha != 0 needs a pre-trust vector"); return ET_E_INVALID_ARG; }
-        hipLaunchKernelGGL(k_step_f64<true>, dim3(n_blocks), dim3(BLOCK_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_step_f64<true>, dim3(grid), dim3(WPB_F64 * 64), lds, st, a);
     } else {
-        hipLaunchKernelGGL(k_step_f64<false>, dim3(n_blocks), dim3(BLOCK_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_step_f64<false>, dim3(grid), dim3(WPB_F64 * 64), lds, st, a);
     }
     HIP_TRY(hipGetLastError());
     return ET_OK;
@@ -583,12 +595,14 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, hipStream
     if (!(variants & ET_VARIANT_FR)) { set_error("graph was built without the Fr variant"); return ET_E_UNSUPPORTED; }
     if (x == y) { set_error("step needs distinct input and output vectors"); return ET_E_INVALID_ARG; }
     StepArgsFr a;
-    a.blocks = d_blocks; a.slices = d_slices; a.col = d_col; a.wlo = d_wlo; a.whi = d_whi; a.x = x; a.y = y;
-    size_t ring = (size_t)(iteration % STATS_RING) * n_blocks;
+    a.work = d_work; a.slices = d_slices; a.col = d_col; a.wlo = d_wlo; a.whi = d_whi; a.x = x; a.y = y;
+    size_t ring = (size_t)(iteration % STATS_RING) * n_work;
     a.sum_part = d_frsum_part + 2 * ring; a.chg_part = d_chg_part + ring;
-    a.geo = geo; a.inv_nm1_w = to_u256(inv_nm1_w);
-    if (n_blocks == 0) return ET_OK;
-    hipLaunchKernelGGL(k_step_fr, dim3(n_blocks), dim3(BLOCK_THREADS), 0, st, a);
+    a.geo = geo; a.n_work = n_work; a.inv_nm1_w = to_u256(inv_nm1_w);
+    if (n_work == 0) return ET_OK;
+    const unsigned grid = (n_work + WPB_FR - 1) / WPB_FR;
+    const size_t lds = (size_t)geo.n_seg * geo.hot_fr * 32;
+    hipLaunchKernelGGL(k_step_fr, dim3(grid), dim3(WPB_FR * 64), lds, st, a);
     HIP_TRY(hipGetLastError());
     return ET_OK;
 }
@@ -604,9 +618,9 @@ int DeviceGraph::unpermute_fr(const uint4* x, uint4* out, hipStream_t st) {
 }
 int DeviceGraph::stats_f64(uint32_t iteration, hipStream_t st, et_iter_stats* out) {
     if (!(variants & ET_VARIANT_F64)) return ET_E_UNSUPPORTED;
-    size_t ring = (size_t)(iteration % STATS_RING) * n_blocks;
+    size_t ring = (size_t)(iteration % STATS_RING) * n_work;
     double* o = (double*)d_stat_out;
-    hipLaunchKernelGGL(k_stats_f64, dim3(1), dim3(64), 0, st, d_res_part + ring, d_sum_part + ring, n_blocks, o);
+    hipLaunchKernelGGL(k_stats_f64, dim3(1), dim3(64), 0, st, d_res_part + ring, d_sum_part + ring, n_work, o);
     HIP_TRY(hipGetLastError());
     double h[2];
     HIP_TRY(hipMemcpyAsync(h, o, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -618,10 +632,10 @@ int DeviceGraph::stats_f64(uint32_t iteration, hipStream_t st, et_iter_stats* ou
 }
 int DeviceGraph::stats_fr(uint32_t iteration, hipStream_t st, et_iter_stats* out) {
     if (!(variants & ET_VARIANT_FR)) return ET_E_UNSUPPORTED;
-    size_t ring = (size_t)(iteration % STATS_RING) * n_blocks;
+    size_t ring = (size_t)(iteration % STATS_RING) * n_work;
     uint4* o = (uint4*)d_stat_out;
     unsigned long long* oc = (unsigned long long*)(o + 2);
-    hipLaunchKernelGGL(k_stats_fr, dim3(1), dim3(64), 0, st, d_frsum_part + 2 * ring, d_chg_part + ring, n_blocks, o, oc);
+    hipLaunchKernelGGL(k_stats_fr, dim3(1), dim3(64), 0, st, d_frsum_part + 2 * ring, d_chg_part + ring, n_work, o, oc);
     HIP_TRY(hipGetLastError());
     uint8_t h[40];
     HIP_TRY(hipMemcpyAsync(h, o, sizeof(h), hipMemcpyDeviceToHost, st));

@@ -20,7 +20,7 @@ struct DeviceGraph {
     int variants = 0;
     uint32_t n = 0, n_valid = 0;
     uint64_t nnz = 0, nnz_local = 0, n_steps = 0;
-    uint32_t n_slices = 0, n_blocks = 0, n_dangling_local = 0;
+    uint32_t n_slices = 0, n_work = 0, n_dangling_local = 0;
     Geometry geo{};
     size_t vec_len = 0;
     uint64_t device_bytes = 0;
@@ -29,7 +29,7 @@ struct DeviceGraph {
     double inv_nm1 = 0.0;
     uint32_t last_iters = 0;
 
-    BlockDesc* d_blocks = nullptr;
+    WorkDesc* d_work = nullptr;
     SliceDesc* d_slices = nullptr;
     uint32_t* d_col = nullptr;
     double* d_w64 = nullptr;

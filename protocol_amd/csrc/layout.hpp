@@ -10,6 +10,9 @@
 // stream is one contiguous 64-lane access.  A row with many in-edges gets a slice of its own whose
 // 64 lanes each hold every 64th edge of that one row and are summed across the wavefront.
 //
+// The peers gathered most often (highest out-degree) are placed first, so that a prefix of every
+// segment can be staged in LDS.
+//
 // Trust vectors live in "position" order: G segments (one per GPU that owns rows; G = 1 on a single
 // GPU), each `rows_cap` row entries followed by `nd_cap` entries holding that GPU's partial sums of
 // the score mass of dangling peers (peers whose filtered row is empty, native.rs:263-278).  An
@@ -33,15 +36,17 @@ struct SliceDesc {
 };
 static const uint32_t SLICE_REDUCE = 0x80000000u;
 
-struct BlockDesc {
-    uint32_t slice_begin, slice_end;  // slices of this workgroup; wave w takes begin+w, begin+w+4, ...
+// Work of ONE wavefront: a contiguous run of slices of one class (active or dangling rows).
+struct WorkDesc {
+    uint32_t slice_begin, slice_end;
     uint32_t flags;                   // bit 0: rows are dangling peers
     uint32_t dslot;                   // slot in the segment's partial-sum tail (flag bit 0 only)
 };
-static const uint32_t BLOCK_DANGLING = 1u;
+static const uint32_t WORK_DANGLING = 1u;
 
-static const int WAVES_PER_BLOCK = 4;
-static const int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
+// A source index in the edge stream: segment in the top 3 bits, local row below.
+static const uint32_t COL_SEG_SHIFT = 29;
+static const uint32_t COL_LOCAL_MASK = (1u << COL_SEG_SHIFT) - 1;
 
 // Geometry of the position space, identical on every GPU of a sharded run.
 struct Geometry {
@@ -53,7 +58,11 @@ struct Geometry {
     uint32_t n_active_pad; // rounded up to 64 * G
     uint32_t n_dangling;   // member peers whose filtered row is empty
     uint32_t n_dangling_pad;
+    // The first hot_* local rows of every segment hold the most frequently gathered sources; the
+    // step kernels keep them in LDS (per variant, because the entry size differs).
+    uint32_t hot_f64, hot_fr;
     ET_HD uint32_t seg_stride() const { return rows_cap + nd_cap; }
+    ET_HD uint32_t pos_of_col(uint32_t c) const { return (c >> COL_SEG_SHIFT) * seg_stride() + (c & COL_LOCAL_MASK); }
 };
 
 }  // namespace et

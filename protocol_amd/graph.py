@@ -42,7 +42,7 @@ class Graph:
 
     def __init__(self, n, frm, to, value_u32=None, value_fr=None, member=None, n_seg=1, seg=0,
                  variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64, device=-1, long_row=0,
-                 target_blocks=0):
+                 target_work=0):
         frm = np.ascontiguousarray(frm, dtype=np.uint32)
         to = np.ascontiguousarray(to, dtype=np.uint32)
         if len(frm) != len(to):
@@ -55,7 +55,7 @@ class Graph:
             member = np.ascontiguousarray(member, dtype=np.uint8)
             if len(member) != n:
                 raise ValueError("member flags must have n entries")
-        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_blocks, variants, device)
+        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, variants, device)
         h = C.c_void_p()
         check(lib().et_graph_build(n, _ptr(member), len(frm), _ptr(frm), _ptr(to), _ptr(value_u32),
                                    _ptr(value_fr), C.byref(opts), C.byref(h)))
@@ -155,7 +155,7 @@ class Plan:
     Arrays are copied into numpy so they outlive the native object."""
 
     def __init__(self, n, frm, to, value_u32=None, value_fr=None, member=None, n_seg=1, seg=0,
-                 long_row=0, target_blocks=0):
+                 long_row=0, target_work=0):
         frm = np.ascontiguousarray(frm, dtype=np.uint32)
         to = np.ascontiguousarray(to, dtype=np.uint32)
         if value_u32 is not None:
@@ -164,7 +164,7 @@ class Plan:
             value_fr = np.ascontiguousarray(value_fr, dtype=np.uint8)
         if member is not None:
             member = np.ascontiguousarray(member, dtype=np.uint8)
-        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_blocks, 0, -1)
+        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, 0, -1)
         h = C.c_void_p()
         check(lib().et_plan_build(n, _ptr(member), len(frm), _ptr(frm), _ptr(to), _ptr(value_u32),
                                   _ptr(value_fr), C.byref(opts), C.byref(h)))
@@ -179,7 +179,7 @@ class Plan:
             vec_len = int(info.vec_len)
             self.pos_of_slot = np.ctypeslib.as_array(arr.pos_of_slot, (n,)).copy()
             self.slices = [(s.off, s.len, s.row0, s.nrows) for s in arr.slices[:info.n_slices]]
-            self.blocks = [(b.slice_begin, b.slice_end, b.flags, b.dslot) for b in arr.blocks[:info.n_blocks]]
+            self.work = [(b.slice_begin, b.slice_end, b.flags, b.dslot) for b in arr.work[:info.n_work]]
             self.col = np.ctypeslib.as_array(arr.col, (slots,)).copy() if slots else np.zeros(0, np.uint32)
             if arr.value_u32:
                 self.value_u32 = np.ctypeslib.as_array(arr.value_u32, (slots,)).copy() if slots else np.zeros(0, np.uint32)

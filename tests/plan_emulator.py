@@ -49,7 +49,7 @@ class SegmentEmulator:
         D = sum(tails) % R if field else float(np.sum(np.array(tails, dtype=np.float64)))
         changed = 0
         total = 0
-        for (sb, se, flags, dslot) in p.blocks:
+        for (sb, se, flags, dslot) in p.work:
             dang = bool(flags & 1)
             dacc = 0
             for s in range(sb, se):
@@ -61,6 +61,7 @@ class SegmentEmulator:
                     for lane in range(64):
                         e = (off + k) * 64 + lane
                         c = int(p.col[e])
+                        c = (c >> 29) * self.stride + (c & 0x1FFFFFFF)   # (segment, local row) -> position
                         if field:
                             v = int(p.value_u32[e]) if p.value_u32 is not None else p.value_fr[e]
                             if v:

@@ -139,13 +139,13 @@ def random_case(seed, n=400):
 
 def test_plan_layout_is_a_faithful_rearrangement():
     n, member, frm, to, val = random_case(1)
-    p = pa.Plan(n, frm, to, value_u32=val, member=member, long_row=16, target_blocks=9)
+    p = pa.Plan(n, frm, to, value_u32=val, member=member, long_row=16, target_work=9)
     pos = p.pos_of_slot
     assert ((pos == 0xFFFFFFFF) == (member == 0)).all()
     assert len(np.unique(pos[member == 1])) == member.sum()     # positions are distinct
     # every slice belongs to exactly one block, blocks are contiguous and ordered
     covered = []
-    for sb, se, flags, dslot in p.blocks:
+    for sb, se, flags, dslot in p.work:
         covered.extend(range(sb, se))
         if flags & 1:
             assert dslot < p.info.nd_cap
@@ -160,7 +160,7 @@ def test_plan_executed_on_cpu_matches_oracle(seed):
     n, member, frm, to, val = random_case(seed, n=250)
     rc, exp, nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=4, initial=1000)
     assert rc == 0
-    em = SegmentEmulator(pa.Plan(n, frm, to, value_u32=val, member=member, long_row=16, target_blocks=5))
+    em = SegmentEmulator(pa.Plan(n, frm, to, value_u32=val, member=member, long_row=16, target_work=5))
     assert em.p.info.nnz == nnz
     x = em.init(1000)
     for _ in range(4):

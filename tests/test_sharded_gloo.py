@@ -39,7 +39,7 @@ def _worker(rank, world, port, case, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n, member, frm, to, val, iters = case
     em = SegmentEmulator(pa.Plan(n, frm, to, value_u32=val, member=member, n_seg=world, seg=rank,
-                                 long_row=16, target_blocks=6))
+                                 long_row=16, target_work=6))
     seg = em.segment_slice()
 
     def all_gather(x, field):
