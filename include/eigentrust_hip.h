@@ -232,6 +232,31 @@ int et_graph_result_fr(et_graph *g, et_fr *out, void *stream);
 int et_graph_result_f64(et_graph *g, double *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Batches of small independent sets (ZK witness generation): n_sets sets of n <= 1024 slots.
+ * One workgroup per set runs the whole converge in a single launch; sets never communicate, so a
+ * batch is split over GPUs by creating one sub-batch per GPU.
+ *   member : n_sets*n flags or NULL (every slot holds a peer)
+ *   values : n_sets*n*n opinions, values[s][i][j] = what Opinion::validate returns for attester i
+ *            about slot j (opinion/native.rs:63-109), as small integers
+ *   out    : n_sets*n scores in slot order; status: per set ET_OK / ET_E_INSUFFICIENT_PEERS
+ *            (native.rs:289) / ET_E_SUM_MISMATCH (native.rs:334)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct et_batch et_batch;
+int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t *member, const uint32_t *values,
+                    int device, et_batch **out);
+void et_batch_free(et_batch *b);
+/* Enqueues the converge of every set on `stream`; allocates nothing, does not synchronise. */
+int et_batch_run_fr_async(et_batch *b, uint32_t num_iterations, uint64_t initial_lo,
+                          uint64_t initial_hi, void *stream);
+int et_batch_result_fr(et_batch *b, et_fr *out, int32_t *status, void *stream);
+/* Sum over sets of n_valid*(n_valid-1): the dense edge count the reference iterates over. */
+int et_batch_edges(const et_batch *b, uint64_t *edges);
+/* create + run + result + free. */
+int et_batch_converge_fr(uint32_t n_sets, uint32_t n, const uint8_t *member, const uint32_t *values,
+                         uint32_t num_iterations, uint64_t initial_lo, uint64_t initial_hi,
+                         et_fr *out, int32_t *status);
+
+/* ------------------------------------------------------------------------------------------
  * Deterministic synthetic attestation lists (benchmarks and parity tests use the same inputs).
  * kind: 2 = uniform out-degree, 3 = power-law out-degree with preferential targets and a share of
  * peers without opinions.  Two-call protocol: with from == NULL only *n_edges is written.

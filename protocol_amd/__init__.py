@@ -6,4 +6,4 @@ Everything computes on the GPU through protocol_amd/lib/libeigentrust_hip.so; th
 from ._ffi import EigenTrustError, LIB_PATH, lib  # noqa: F401
 from .eigentrust_set import (EigenTrustSet, INITIAL_SCORE, MIN_PEER_COUNT, NUM_ITERATIONS,  # noqa: F401
                              NUM_NEIGHBOURS)
-from .graph import Graph, Plan, R_MODULUS, fr_bytes_from_ints, fr_ints_from_bytes, synth_graph  # noqa: F401
+from .graph import Batch, Graph, Plan, R_MODULUS, fr_bytes_from_ints, fr_ints_from_bytes, synth_graph  # noqa: F401

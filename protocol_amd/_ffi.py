@@ -112,6 +112,12 @@ PROTOTYPES = {
     "et_graph_event_times": (i32, [vp, P(C.c_float), P(u32)]),
     "et_graph_result_fr": (i32, [vp, vp, vp]),
     "et_graph_result_f64": (i32, [vp, vp, vp]),
+    "et_batch_create": (i32, [u32, u32, vp, vp, i32, P(vp)]),
+    "et_batch_free": (None, [vp]),
+    "et_batch_run_fr_async": (i32, [vp, u32, u64, u64, vp]),
+    "et_batch_result_fr": (i32, [vp, vp, vp, vp]),
+    "et_batch_edges": (i32, [vp, P(u64)]),
+    "et_batch_converge_fr": (i32, [u32, u32, vp, vp, u32, u64, u64, vp, vp]),
     "et_synth_graph": (i32, [u32, u32, u64, u64, u32, P(u64), vp, vp, vp]),
     "et_dev_fr_mul": (i32, [u32, vp, vp, vp]),
 }

@@ -1,0 +1,388 @@
+// Batches of small independent sets (ZK witness generation: thousands of 256-peer sets).
+//
+// One workgroup per set; the whole converge of a set (dynamic_sets/native.rs:286-337) runs in ONE
+// launch: the trust vector lives in LDS for all iterations and, when the opinions fit a byte (the
+// production range, eigentrust/src/attestation.rs:304), so does the set's opinion matrix.
+// Sets never communicate, so a batch is split over GPUs by giving each its own sub-batch.
+//
+// The dense row of ones of a peer without valid opinions (native.rs:263-278) is evaluated as the
+// rank-1 term (D - dangling_i * s_i) / (n_valid - 1), exactly as in the graph engine, and the
+// normalisation is folded into the vector: xs_j = s_j * inv(sum_j), new_s_i = sum_j v_ji * xs_j.
+// Field arithmetic is exact and distributive, so this equals the reference's
+// sum_j (v_ji * inv(sum_j)) * s_j bit for bit.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/eigentrust_hip.h"
+#include "engine.hpp"
+#include "fr_dev.hpp"
+#include "fr_host.hpp"
+
+namespace et {
+
+#define HIP_TRY_B(expr)                                                               \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));             \
+            return _e == hipErrorNoDevice ? ET_E_NO_DEVICE : ET_E_HIP;                \
+        }                                                                             \
+    } while (0)
+
+static const int BATCH_THREADS = 256;
+
+// 320-bit accumulator for sums of (32-bit opinion) x (field element): holds 2^34 such products
+struct Acc10 {
+    uint32_t v[10];
+};
+ET_DEV void acc10_mac_u32(Acc10& acc, const U256& a, uint32_t v) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uint64_t t = (uint64_t)a.v[j] * v + acc.v[j] + c;
+        acc.v[j] = (uint32_t)t;
+        c = t >> 32;
+    }
+    uint64_t t = (uint64_t)acc.v[8] + c;
+    acc.v[8] = (uint32_t)t;
+    acc.v[9] += (uint32_t)(t >> 32);
+}
+
+struct BatchArgs {
+    const void* vals;        // n_sets * n * n opinions, row-major (row = attester), uint8 or uint32
+    const uint8_t* member;   // n_sets * n
+    const uint8_t* dangling; // n_sets * n : member whose filtered row sums to zero
+    const uint4* scale;      // n_sets * n : inv(row sum) * 2^576 mod r (zero for dangling / empty)
+    const uint4* inv_nm1_w;  // n_sets     : inv(n_valid - 1) * 2^288 mod r
+    const int32_t* pre_status; // n_sets   : ET_OK or ET_E_INSUFFICIENT_PEERS
+    uint4* out;              // n_sets * n scores
+    int32_t* status;         // n_sets
+    uint32_t n, num_iter;
+    U256 initial;
+};
+
+template <typename VT, bool VALS_IN_LDS>
+__global__ __launch_bounds__(BATCH_THREADS) void k_batch_fr(BatchArgs a) {
+    extern __shared__ uint4 lds4[];
+    const uint32_t n = a.n;
+    // LDS carve-up: s[n], next s[n], xs[n] (2 x uint4 each), reduction scratch, optional opinion matrix
+    uint4* s_l = lds4;
+    uint4* sn_l = lds4 + 2 * (size_t)n;
+    uint4* xs_l = lds4 + 4 * (size_t)n;
+    uint4* red_l = lds4 + 6 * (size_t)n;              // 2 * 4 waves
+    VT* v_l = reinterpret_cast<VT*>(red_l + 2 * 4 + 2);
+    __shared__ uint32_t sh_D[8];
+    const uint32_t set = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const VT* vg = reinterpret_cast<const VT*>(a.vals) + (size_t)set * n * n;
+    const uint8_t* mem = a.member + (size_t)set * n;
+    const uint8_t* dng = a.dangling + (size_t)set * n;
+    uint4* outp = a.out + 2 * (size_t)set * n;
+
+    if (a.pre_status[set] != ET_OK) {
+        for (uint32_t i = threadIdx.x; i < n; i += BATCH_THREADS) u256_store(outp + 2 * i, u256_zero());
+        if (threadIdx.x == 0) a.status[set] = a.pre_status[set];
+        return;
+    }
+    if (VALS_IN_LDS) {
+        const size_t total = (size_t)n * n;
+        for (size_t t = threadIdx.x; t < total; t += BATCH_THREADS) v_l[t] = vg[t];
+    }
+    const VT* vsrc = VALS_IN_LDS ? v_l : vg;
+    const U256 inw = u256_load(a.inv_nm1_w + 2 * (size_t)set);
+    uint32_t n_valid_local = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += BATCH_THREADS) {
+        u256_store(s_l + 2 * i, mem[i] ? a.initial : u256_zero());   // native.rs:317
+        n_valid_local += mem[i] != 0;
+    }
+    __syncthreads();
+
+    for (uint32_t it = 0; it < a.num_iter; ++it) {
+        // phase 1: xs_j = s_j * inv(sum_j) * 2^288, and the score mass of dangling peers
+        U256 dpart = u256_zero();
+        for (uint32_t i = threadIdx.x; i < n; i += BATCH_THREADS) {
+            U256 si = u256_load(s_l + 2 * i);
+            U256 k = u256_load(a.scale + 2 * ((size_t)set * n + i));
+            Acc t = acc_zero();
+            acc_mac(t, si, k);
+            u256_store(xs_l + 2 * i, acc_redc288(t));
+            if (dng[i]) dpart = fr_add(dpart, si);
+        }
+        // workgroup sum of dpart, fixed order
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            U256 o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o.v[q] = __shfl_xor(dpart.v[q], off, 64);
+            dpart = fr_add(dpart, o);
+        }
+        if (lane == 0) u256_store(red_l + 2 * wave, dpart);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            U256 d = u256_zero();
+            for (int w = 0; w < BATCH_THREADS / 64; ++w) d = fr_add(d, u256_load(red_l + 2 * w));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sh_D[q] = d.v[q];
+        }
+        __syncthreads();
+        U256 D;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) D.v[q] = sh_D[q];
+        // phase 2: new_s_i = sum_{j != i} v_ji * xs_j + (D - dangling_i * s_i) * inv(n_valid-1)
+        for (uint32_t i = threadIdx.x; i < n; i += BATCH_THREADS) {
+            U256 v = u256_zero();
+            if (mem[i]) {
+                Acc10 acc;
+#pragma unroll
+                for (int q = 0; q < 10; ++q) acc.v[q] = 0;
+                for (uint32_t j = 0; j < n; ++j) {
+                    uint32_t op = (uint32_t)vsrc[(size_t)j * n + i];
+                    op = j == i ? 0u : op;                       // native.rs:254-259 (self opinion)
+                    U256 xj = u256_load(xs_l + 2 * j);           // same address in every lane: LDS broadcast
+                    acc10_mac_u32(acc, xj, op);
+                }
+                Acc full = acc_zero();
+#pragma unroll
+                for (int q = 0; q < 10; ++q) full.v[q] = acc.v[q];
+                U256 si = u256_load(s_l + 2 * i);
+                U256 t = dng[i] ? fr_sub(D, si) : D;
+                acc_mac(full, inw, t);
+                v = acc_redc288(full);
+            }
+            u256_store(sn_l + 2 * i, v);
+        }
+        __syncthreads();
+        uint4* tmp = s_l; s_l = sn_l; sn_l = tmp;
+    }
+    // output + conservation check (native.rs:331-334): sum of scores == INITIAL * n_valid
+    U256 tot = u256_zero();
+    for (uint32_t i = threadIdx.x; i < n; i += BATCH_THREADS) {
+        U256 si = u256_load(s_l + 2 * i);
+        u256_store(outp + 2 * i, si);
+        tot = fr_add(tot, si);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        U256 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o.v[q] = __shfl_xor(tot.v[q], off, 64);
+        tot = fr_add(tot, o);
+        n_valid_local += __shfl_xor(n_valid_local, off, 64);
+    }
+    __shared__ uint32_t sh_nv[BATCH_THREADS / 64];
+    if (lane == 0) { u256_store(red_l + 2 * wave, tot); sh_nv[wave] = n_valid_local; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        U256 t = u256_zero();
+        uint32_t nv = 0;
+        for (int w = 0; w < BATCH_THREADS / 64; ++w) { t = fr_add(t, u256_load(red_l + 2 * w)); nv += sh_nv[w]; }
+        U256 expect = u256_zero();
+        for (uint32_t k = 0; k < nv; ++k) expect = fr_add(expect, a.initial);   // nv <= 1024
+        a.status[set] = u256_eq(t, expect) ? ET_OK : ET_E_SUM_MISMATCH;
+    }
+}
+
+struct DeviceBatch {
+    int device = -1;
+    uint32_t n_sets = 0, n = 0;
+    bool vals_u8 = false;
+    void* d_vals = nullptr;
+    uint8_t* d_member = nullptr;
+    uint8_t* d_dangling = nullptr;
+    uint4* d_scale = nullptr;
+    uint4* d_inw = nullptr;
+    int32_t* d_pre = nullptr;
+    uint4* d_out = nullptr;
+    int32_t* d_status = nullptr;
+    uint64_t edges = 0;   // sum over sets of n_valid * (n_valid - 1): dense edge count of the reference
+    ~DeviceBatch() {
+        if (device >= 0) (void)hipSetDevice(device);
+        void* p[] = {d_vals, d_member, d_dangling, d_scale, d_inw, d_pre, d_out, d_status};
+        for (void* q : p) if (q) (void)hipFree(q);
+    }
+};
+
+template <typename F>
+static void parallel_sets(uint32_t n, F f) {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned nt = std::max(1u, std::min(16u, hw ? hw : 1u));
+    if (n < 8) nt = 1;
+    std::atomic<uint32_t> next(0);
+    auto work = [&]() { for (;;) { uint32_t i = next.fetch_add(1); if (i >= n) break; f(i); } };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+}
+
+static U256 to_u256b(const FrRaw& r) {
+    U256 u;
+    for (int i = 0; i < 4; ++i) { u.v[2 * i] = (uint32_t)r.l[i]; u.v[2 * i + 1] = (uint32_t)(r.l[i] >> 32); }
+    return u;
+}
+
+static size_t batch_lds_bytes(uint32_t n, bool vals_in_lds, size_t vsize) {
+    size_t b = (6 * (size_t)n + 2 * 4 + 2) * sizeof(uint4);
+    if (vals_in_lds) b += (size_t)n * n * vsize;
+    return b;
+}
+
+}  // namespace et
+
+using namespace et;
+struct et_batch {
+    DeviceBatch b;
+};
+
+extern "C" {
+
+int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const uint32_t* values, int device, et_batch** out) {
+    if (!out || !values || n_sets == 0 || n == 0) return ET_E_INVALID_ARG;
+    if (n > 1024) { set_error("a batched set holds at most 1024 slots"); return ET_E_UNSUPPORTED; }
+    int ndev = 0;
+    HIP_TRY_B(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { set_error("no HIP device"); return ET_E_NO_DEVICE; }
+    if (device < 0) HIP_TRY_B(hipGetDevice(&device));
+    HIP_TRY_B(hipSetDevice(device));
+    const size_t rows = (size_t)n_sets * n;
+    std::vector<uint8_t> mem(rows), dang(rows, 0);
+    std::vector<FrRaw> scale(rows, FrRaw{{0, 0, 0, 0}}), inw(n_sets, FrRaw{{0, 0, 0, 0}});
+    std::vector<int32_t> pre(n_sets, ET_OK);
+    std::vector<uint64_t> edges(n_sets, 0);
+    std::atomic<uint32_t> vmax(0);
+    // filter_peers_ops + row sums + inversion, one set per task (native.rs:234-283, :305-309)
+    parallel_sets(n_sets, [&](uint32_t s) {
+        const uint32_t* v = values + (size_t)s * n * n;
+        uint8_t* m = mem.data() + (size_t)s * n;
+        uint32_t nv = 0, local_max = 0;
+        for (uint32_t i = 0; i < n; ++i) { m[i] = member ? member[(size_t)s * n + i] != 0 : 1; nv += m[i]; }
+        if (nv < 2) { pre[s] = ET_E_INSUFFICIENT_PEERS; return; }
+        edges[s] = (uint64_t)nv * (nv - 1);
+        std::vector<Fr> sums(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            uint64_t sum = 0;
+            if (m[i]) for (uint32_t j = 0; j < n; ++j) if (j != i && m[j]) { sum += v[(size_t)i * n + j]; local_max = std::max(local_max, v[(size_t)i * n + j]); }
+            if (m[i] && sum == 0) dang[(size_t)s * n + i] = 1;
+            sums[i] = Fr::from_u64(sum);
+        }
+        fr_batch_invert(sums);
+        const Fr two576 = Fr::one().pow2k(576);
+        for (uint32_t i = 0; i < n; ++i) if (m[i] && !dang[(size_t)s * n + i]) scale[(size_t)s * n + i] = (sums[i] * two576).to_raw();
+        inw[s] = (Fr::from_u64(nv - 1).invert_or_zero() * Fr::one().pow2k(288)).to_raw();
+        uint32_t cur = vmax.load();
+        while (local_max > cur && !vmax.compare_exchange_weak(cur, local_max)) {}
+    });
+    std::unique_ptr<et_batch> h(new et_batch());
+    DeviceBatch& b = h->b;
+    b.device = device; b.n_sets = n_sets; b.n = n;
+    for (uint64_t e : edges) b.edges += e;
+    // opinions about empty slots or from empty slots never count: zero them once here so the
+    // kernel only has to skip the diagonal
+    const size_t cells = rows * n;
+    b.vals_u8 = vmax.load() <= 255;
+    if (b.vals_u8) {
+        std::vector<uint8_t> v8(cells);
+        parallel_sets(n_sets, [&](uint32_t s) {
+            const uint32_t* v = values + (size_t)s * n * n;
+            const uint8_t* m = mem.data() + (size_t)s * n;
+            uint8_t* o = v8.data() + (size_t)s * n * n;
+            for (uint32_t i = 0; i < n; ++i) for (uint32_t j = 0; j < n; ++j) o[(size_t)i * n + j] = (m[i] && m[j] && i != j) ? (uint8_t)v[(size_t)i * n + j] : 0;
+        });
+        HIP_TRY_B(hipMalloc(&b.d_vals, cells));
+        HIP_TRY_B(hipMemcpy(b.d_vals, v8.data(), cells, hipMemcpyHostToDevice));
+    } else {
+        std::vector<uint32_t> v32(cells);
+        parallel_sets(n_sets, [&](uint32_t s) {
+            const uint32_t* v = values + (size_t)s * n * n;
+            const uint8_t* m = mem.data() + (size_t)s * n;
+            uint32_t* o = v32.data() + (size_t)s * n * n;
+            for (uint32_t i = 0; i < n; ++i) for (uint32_t j = 0; j < n; ++j) o[(size_t)i * n + j] = (m[i] && m[j] && i != j) ? v[(size_t)i * n + j] : 0;
+        });
+        HIP_TRY_B(hipMalloc(&b.d_vals, cells * 4));
+        HIP_TRY_B(hipMemcpy(b.d_vals, v32.data(), cells * 4, hipMemcpyHostToDevice));
+    }
+    HIP_TRY_B(hipMalloc((void**)&b.d_member, rows));
+    HIP_TRY_B(hipMalloc((void**)&b.d_dangling, rows));
+    HIP_TRY_B(hipMalloc((void**)&b.d_scale, rows * 32));
+    HIP_TRY_B(hipMalloc((void**)&b.d_inw, (size_t)n_sets * 32));
+    HIP_TRY_B(hipMalloc((void**)&b.d_pre, (size_t)n_sets * 4));
+    HIP_TRY_B(hipMalloc((void**)&b.d_out, rows * 32));
+    HIP_TRY_B(hipMalloc((void**)&b.d_status, (size_t)n_sets * 4));
+    HIP_TRY_B(hipMemcpy(b.d_member, mem.data(), rows, hipMemcpyHostToDevice));
+    HIP_TRY_B(hipMemcpy(b.d_dangling, dang.data(), rows, hipMemcpyHostToDevice));
+    HIP_TRY_B(hipMemcpy(b.d_scale, scale.data(), rows * 32, hipMemcpyHostToDevice));
+    HIP_TRY_B(hipMemcpy(b.d_inw, inw.data(), (size_t)n_sets * 32, hipMemcpyHostToDevice));
+    HIP_TRY_B(hipMemcpy(b.d_pre, pre.data(), (size_t)n_sets * 4, hipMemcpyHostToDevice));
+    *out = h.release();
+    return ET_OK;
+}
+
+void et_batch_free(et_batch* b) { delete b; }
+
+int et_batch_run_fr_async(et_batch* h, uint32_t num_iterations, uint64_t initial_lo, uint64_t initial_hi, void* stream) {
+    if (!h) return ET_E_INVALID_ARG;
+    DeviceBatch& b = h->b;
+    BatchArgs a;
+    a.vals = b.d_vals; a.member = b.d_member; a.dangling = b.d_dangling; a.scale = b.d_scale; a.inv_nm1_w = b.d_inw;
+    a.pre_status = b.d_pre; a.out = b.d_out; a.status = b.d_status; a.n = b.n; a.num_iter = num_iterations;
+    a.initial = to_u256b(Fr::from_u128(initial_lo, initial_hi).to_raw());
+    const size_t budget = 150 * 1024;
+    hipStream_t st = (hipStream_t)stream;
+    if (b.vals_u8) {
+        bool in_lds = batch_lds_bytes(b.n, true, 1) <= budget;
+        size_t lds = batch_lds_bytes(b.n, in_lds, 1);
+        if (in_lds) {
+            HIP_TRY_B(hipFuncSetAttribute((const void*)k_batch_fr<uint8_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget));
+            hipLaunchKernelGGL((k_batch_fr<uint8_t, true>), dim3(b.n_sets), dim3(BATCH_THREADS), lds, st, a);
+        } else {
+            hipLaunchKernelGGL((k_batch_fr<uint8_t, false>), dim3(b.n_sets), dim3(BATCH_THREADS), lds, st, a);
+        }
+    } else {
+        bool in_lds = batch_lds_bytes(b.n, true, 4) <= budget;
+        size_t lds = batch_lds_bytes(b.n, in_lds, 4);
+        if (in_lds) {
+            HIP_TRY_B(hipFuncSetAttribute((const void*)k_batch_fr<uint32_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget));
+            hipLaunchKernelGGL((k_batch_fr<uint32_t, true>), dim3(b.n_sets), dim3(BATCH_THREADS), lds, st, a);
+        } else {
+            hipLaunchKernelGGL((k_batch_fr<uint32_t, false>), dim3(b.n_sets), dim3(BATCH_THREADS), lds, st, a);
+        }
+    }
+    HIP_TRY_B(hipGetLastError());
+    return ET_OK;
+}
+
+int et_batch_result_fr(et_batch* h, et_fr* out, int32_t* status, void* stream) {
+    if (!h || !out) return ET_E_INVALID_ARG;
+    DeviceBatch& b = h->b;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY_B(hipMemcpyAsync(out, b.d_out, (size_t)b.n_sets * b.n * 32, hipMemcpyDeviceToHost, st));
+    if (status) HIP_TRY_B(hipMemcpyAsync(status, b.d_status, (size_t)b.n_sets * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY_B(hipStreamSynchronize(st));
+    return ET_OK;
+}
+
+int et_batch_edges(const et_batch* h, uint64_t* edges) {
+    if (!h || !edges) return ET_E_INVALID_ARG;
+    *edges = h->b.edges;
+    return ET_OK;
+}
+
+int et_batch_converge_fr(uint32_t n_sets, uint32_t n, const uint8_t* member, const uint32_t* values, uint32_t num_iterations,
+                         uint64_t initial_lo, uint64_t initial_hi, et_fr* out, int32_t* status) {
+    et_batch* b = nullptr;
+    int rc = et_batch_create(n_sets, n, member, values, -1, &b);
+    if (rc) return rc;
+    rc = et_batch_run_fr_async(b, num_iterations, initial_lo, initial_hi, nullptr);
+    if (!rc) rc = et_batch_result_fr(b, out, status, nullptr);
+    et_batch_free(b);
+    return rc;
+}
+
+}  // extern "C"

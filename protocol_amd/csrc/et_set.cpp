@@ -190,6 +190,27 @@ static int build_for_set(const et_set* s, int variants, DeviceGraph** out) {
 
 int et_set_converge(et_set* s, et_fr* out) {
     if (!s || !out) return ET_E_INVALID_ARG;
+    {
+        uint32_t valid = 0;                                             // native.rs:288-289
+        for (uint32_t i = 0; i < s->n; ++i) valid += !s->addr[i].is_zero();
+        if (valid < 2) { set_error("Insufficient peers for calculation!"); return ET_E_INSUFFICIENT_PEERS; }
+    }
+    if (s->n <= 1024 && s->all_u32) {
+        // small set: one workgroup runs the whole converge in a single launch (batch of one)
+        std::vector<uint8_t> member(s->n);
+        std::vector<uint32_t> dense((size_t)s->n * s->n, 0);
+        for (uint32_t i = 0; i < s->n; ++i) {
+            member[i] = !s->addr[i].is_zero();
+            if (member[i] && s->has_row[i])
+                for (auto& kv : s->rows[i]) dense[(size_t)i * s->n + kv.first] = (uint32_t)kv.second.l[0];
+        }
+        int32_t status = ET_OK;
+        int rc = et_batch_converge_fr(1, s->n, member.data(), dense.data(), s->num_iter, s->init_lo, s->init_hi, out, &status);
+        if (rc) return rc;
+        if (status == ET_E_INSUFFICIENT_PEERS) set_error("Insufficient peers for calculation!");
+        if (status == ET_E_SUM_MISMATCH) set_error("reputation leak: field sum of scores changed");
+        return status;
+    }
     DeviceGraph* gp = nullptr;
     int rc = build_for_set(s, ET_VARIANT_FR, &gp);
     if (rc) return rc;

@@ -196,3 +196,48 @@ class Plan:
             self.n_dangling_pad, self.n_dangling_local = arr.n_dangling_pad, arr.n_dangling_local
         finally:
             lib().et_plan_free(h)
+
+
+class Batch:
+    """Many small independent sets resident on one GPU (et_batch_*); one workgroup per set."""
+
+    def __init__(self, values, member=None, device=-1):
+        values = np.ascontiguousarray(values, dtype=np.uint32)
+        if values.ndim != 3 or values.shape[1] != values.shape[2]:
+            raise ValueError("values must have shape [n_sets, n, n]")
+        self.n_sets, self.n = int(values.shape[0]), int(values.shape[1])
+        if member is not None:
+            member = np.ascontiguousarray(member, dtype=np.uint8)
+            if member.shape != (self.n_sets, self.n):
+                raise ValueError("member must have shape [n_sets, n]")
+        h = C.c_void_p()
+        check(lib().et_batch_create(self.n_sets, self.n, _ptr(member), _ptr(values), device, C.byref(h)))
+        self._h = h
+        e = C.c_uint64(0)
+        check(lib().et_batch_edges(self._h, C.byref(e)))
+        self.edges = e.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().et_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run_fr(self, num_iterations=20, initial=1000, stream=None):
+        check(lib().et_batch_run_fr_async(self._h, num_iterations, initial & (2**64 - 1), initial >> 64, stream))
+
+    def result_fr(self, stream=None):
+        """(scores uint8 [n_sets, n, 32], status int32 [n_sets])."""
+        out = np.zeros((self.n_sets, self.n, 32), dtype=np.uint8)
+        status = np.zeros(self.n_sets, dtype=np.int32)
+        check(lib().et_batch_result_fr(self._h, _ptr(out), _ptr(status), stream))
+        return out, status
+
+    def converge_fr(self, num_iterations=20, initial=1000):
+        self.run_fr(num_iterations, initial)
+        return self.result_fr()

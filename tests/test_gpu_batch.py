@@ -1,0 +1,59 @@
+"""Batched small sets (one workgroup per set) against the dense CPU restatement, bit for bit."""
+import numpy as np
+import pytest
+
+import c_oracle
+import eigentrust_ref as ref
+import protocol_amd as pa
+
+pytestmark = pytest.mark.gpu
+
+
+def dense_expect(values, member, iters, initial):
+    n = values.shape[0]
+    rows = [[int(v) for v in values[i]] for i in range(n)]
+    return c_oracle.dense_converge_fr(n, iters, initial, member, member, rows)
+
+
+@pytest.mark.parametrize("n,n_sets,vmax", [(4, 9, 255), (12, 5, 1000), (64, 6, 255), (256, 8, 255), (256, 3, 2**32 - 1),
+                                          (300, 2, 255), (700, 1, 70000)])
+def test_batch_matches_dense_restatement(n, n_sets, vmax):
+    rng = np.random.default_rng(n * 7 + n_sets)
+    values = rng.integers(0, vmax + 1, (n_sets, n, n), dtype=np.uint64).astype(np.uint32)
+    member = (rng.random((n_sets, n)) > 0.06).astype(np.uint8)
+    member[:, :2] = 1
+    values[rng.random((n_sets, n)) < 0.05] = 0          # all-zero rows -> dangling peers
+    values[0, 1, :] = 0
+    if n_sets > 2:
+        member[2, :] = 0
+        member[2, 0] = 1                                 # a single peer: insufficient
+    b = pa.Batch(values, member)
+    out, status = b.converge_fr(20, 1000)
+    for s in range(n_sets):
+        rc, exp, _ = dense_expect(values[s], member[s], 20, 1000)
+        if rc == -1:
+            assert status[s] == pa._ffi.ET_E_INSUFFICIENT_PEERS
+            continue
+        assert rc == 0 and status[s] == 0
+        assert pa.fr_ints_from_bytes(out[s]) == exp, (n, s)
+
+
+def test_batch_reproduces_reference_test_matrices(scenarios):
+    for name in ("test_scaling_1", "closed_graph_5", "threshold_4"):
+        sc = next(s for s in scenarios if s["name"] == name)
+        n = sc["num_neighbours"]
+        rows = [[int(v, 16) for v in st[2]] for st in sc["steps"] if st[0] == "op"]
+        values = np.array([rows], dtype=np.uint32)
+        out, status = pa.Batch(values).converge_fr(sc["num_iterations"], sc["initial_score"])
+        assert status[0] == 0
+        assert [hex(v) for v in pa.fr_ints_from_bytes(out[0])] == sc["checkpoints"][0]["scores_fr"]
+
+
+def test_batch_huge_initial_score():
+    rng = np.random.default_rng(1)
+    values = rng.integers(0, 256, (2, 8, 8), dtype=np.uint32)
+    init = 2**127 + 12345
+    out, status = pa.Batch(values).converge_fr(20, init)
+    for s in range(2):
+        rc, exp, _ = dense_expect(values[s], np.ones(8, dtype=np.uint8), 20, init)
+        assert rc == 0 and status[s] == 0 and pa.fr_ints_from_bytes(out[s]) == exp
