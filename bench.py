@@ -94,6 +94,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    # HBM/fabric traffic per launch measured with PMC counters in a separate profiling run of this
+    # same workload (rocprofv3 cannot be nested inside the bench); null when no such record exists
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    if world == 1 and os.path.exists(tpath):
+        with open(tpath) as f:
+            rec = json.load(f)
+        if rec.get("workload") == wl:
+            traffic = {k: v["traffic_bytes"] for k, v in rec["kernels"].items()}
+
     results = {}
     for variant in (["f64", "fr"] if args.variant == "both" else [args.variant]):
         if variant == "f64":
@@ -127,8 +137,9 @@ def main():
             "value": nnz * NUM_ITER * args.steps / elapsed,
             "ms_per_step": elapsed / args.steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_step_f64" if variant == "f64" else "k_step_fr",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic.get("k_step_f64" if variant == "f64" else "k_step_fr"),
+                         "kernel": "k_step_f64_blocked" if variant == "f64" else "k_step_fr",
                          "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": alg},
         }
 

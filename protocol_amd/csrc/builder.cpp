@@ -170,6 +170,15 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     }
     geo.hot_f64 = std::min<uint32_t>(geo.rows_cap, (opt.hot_f64 / G) / 64 * 64);
     geo.hot_fr = std::min<uint32_t>(geo.rows_cap, (opt.hot_fr / G) / 64 * 64);
+    {
+        // f64 workgroups: one per CU unless the rows of a workgroup would not fit its LDS accumulators
+        const uint32_t n_groups = geo.rows_cap / 64, rb_max = 16384;
+        uint32_t B = std::max<uint32_t>(1, std::min<uint32_t>(opt.f64_blocks ? opt.f64_blocks : 256, n_groups));
+        B = std::max<uint32_t>(B, (geo.rows_cap + rb_max - 1) / rb_max);
+        geo.f64_blocks = B;
+        geo.f64_rb = std::max<uint32_t>(64, (n_groups + B - 1) / B * 64);
+        geo.nd_cap = std::max<uint32_t>(geo.nd_cap, (B + 15) / 16 * 16);
+    }
     g.geo = geo;
     if (G > 8 || geo.seg_stride() >= COL_LOCAL_MASK) {
         err = "more than 8 segments or more than 2^29 rows per segment";
@@ -223,9 +232,20 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     g.nnz_local = in_ptr[geo.rows_cap];
     std::vector<uint32_t> e_src(g.nnz_local);   // source, encoded (segment << 29) | local row
     std::vector<uint64_t> e_idx(g.nnz_local);   // original edge index (for the value)
+    // the same edges grouped by f64 workgroup (64-row groups dealt round-robin), ascending by source
+    const uint32_t B = geo.f64_blocks;
+    g.bk_ptr.assign((size_t)B + 1, 0);
+    for (uint32_t lr = 0; lr < geo.rows_cap; ++lr) g.bk_ptr[(lr >> 6) % B + 1] += in_ptr[lr + 1] - in_ptr[lr];
+    for (uint32_t b = 0; b < B; ++b) g.bk_ptr[b + 1] += g.bk_ptr[b];
+    g.bk_col.resize(g.nnz_local);
+    g.bk_row.resize(g.nnz_local);
+    if (g.values_are_u32) g.bk_val_u32.resize(g.nnz_local);
+    else g.bk_val_fr.resize(g.nnz_local);
     {
-        // visit attesters in ascending POSITION so that every row's sources come out sorted
+        // visit attesters in ascending POSITION so that every row's (and every workgroup's) sources
+        // come out sorted
         std::vector<uint64_t> cur(in_ptr.begin(), in_ptr.end() - 1);
+        std::vector<uint64_t> bcur(g.bk_ptr.begin(), g.bk_ptr.end() - 1);
         std::vector<uint32_t> by_pos(order.begin(), order.begin() + n_active);
         std::sort(by_pos.begin(), by_pos.end(), [&](uint32_t a, uint32_t b) { return g.pos_of_ext[a] < g.pos_of_ext[b]; });
         for (uint32_t f : by_pos) {
@@ -238,6 +258,12 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
                 uint64_t p = cur[lr]++;
                 e_src[p] = pf;
                 e_idx[p] = kept[k];
+                const uint32_t grp = lr >> 6;
+                uint64_t q = bcur[grp % B]++;
+                g.bk_col[q] = pf;
+                g.bk_row[q] = (uint16_t)((grp / B) * 64 + (lr & 63));
+                if (g.values_are_u32) g.bk_val_u32[q] = in.val_u32[kept[k]];
+                else g.bk_val_fr[q] = in.val_fr[kept[k]];
             }
         }
     }

@@ -36,6 +36,7 @@ struct BuildOpts {
     uint32_t long_row = 128;     // in-degree above which a row is spread over a whole wavefront
     uint32_t target_work = 16384; // wavefront work items per iteration launch (several rounds of 256 CUs x 16 waves)
     uint32_t hot_f64 = 16384;    // LDS-resident sources, f64 variant (128 KiB of doubles)
+    uint32_t f64_blocks = 256;   // workgroups of the f64 variant (one per CU)
     uint32_t hot_fr = 0;         // LDS-resident sources, Fr variant (0 = off: measured no gain, the misses are cold sources)
 };
 
@@ -53,6 +54,13 @@ struct HostGraph {
     std::vector<uint32_t> col;          // n_steps*64 sources, (segment << 29) | local row
     std::vector<uint32_t> val_u32;      // n_steps*64 raw opinions (values_are_u32)
     std::vector<FrRaw> val_fr;          // n_steps*64 raw opinions (!values_are_u32)
+    // f64 variant ("blocked sweep"): per workgroup b the edges of its rows, ascending by source
+    // position; entries bk_ptr[b] .. bk_ptr[b+1].
+    std::vector<uint64_t> bk_ptr;
+    std::vector<uint32_t> bk_col;       // source, (segment << 29) | local row
+    std::vector<uint16_t> bk_row;       // row inside the workgroup's accumulator array
+    std::vector<uint32_t> bk_val_u32;   // raw opinions (values_are_u32)
+    std::vector<FrRaw> bk_val_fr;
     // Per-position source factors (zero for dangling / non-member / padding positions):
     std::vector<FrRaw> scale_fr;        // inv(row sum) * 2^576 mod r
     std::vector<double> scale_f64;      // 1 / integer row sum

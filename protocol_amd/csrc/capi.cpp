@@ -76,6 +76,7 @@ static void read_env(BuildOpts& bo) {
     if (const char* e = getenv("ET_HOT_F64")) bo.hot_f64 = (uint32_t)atoi(e);
     if (const char* e = getenv("ET_HOT_FR")) bo.hot_fr = (uint32_t)atoi(e);
     if (const char* e = getenv("ET_LONG_ROW")) bo.long_row = (uint32_t)atoi(e);
+    if (const char* e = getenv("ET_F64_BLOCKS")) bo.f64_blocks = (uint32_t)atoi(e);
 }
 
 int et_plan_build(uint32_t n, const uint8_t* member, uint64_t n_edges, const uint32_t* from, const uint32_t* to,

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -232,6 +233,110 @@ __global__ __launch_bounds__(WPB_F64 * 64) void k_step_f64(StepArgsF64 a) {
         a.res_part[gw] = res;
         a.sum_part[gw] = tot;
         if (dang) a.y[my_base + a.geo.rows_cap + wd.dslot] = dacc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// f64 variant, "blocked sweep".  One 1024-thread workgroup per CU owns geo.f64_rb rows (64-row
+// groups dealt round-robin, so every workgroup gets the same degree mix) with their accumulators in
+// LDS, and walks its edges in ascending SOURCE order: the edge records stream in coalesced, each
+// edge costs one 8-byte gather and one LDS atomic add.  Because every workgroup sweeps the source
+// range at the same pace, the part of the trust vector being gathered at any moment is a narrow
+// window that stays resident in the 4 MiB per-XCD L2 although the whole vector does not fit, and
+// the many consecutive edges of a popular source read one address.  (Measured: the row-per-lane
+// kernel above re-fetches the vector ~7x per XCD and iteration; see DESIGN.md.)
+// The LDS adds of one row arrive in no fixed order, so the last bits of an f64 score can differ
+// from run to run; the Fr variant is exact.
+// ---------------------------------------------------------------------------------------------
+struct StepArgsF64B {
+    const uint64_t* bk_ptr;
+    const uint32_t* col;
+    const double* w;
+    const uint16_t* row;
+    const double* x;
+    double* y;
+    const double* pretrust;
+    double* res_part;   // [f64_blocks]
+    double* sum_part;
+    Geometry geo;
+    double inv_nm1;
+    double alpha;
+};
+
+template <bool HAS_ALPHA>
+__global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
+    extern __shared__ double acc_l[];
+    __shared__ double red[3][16];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x;
+    const uint32_t B = a.geo.f64_blocks, RB = a.geo.f64_rb;
+    const uint32_t stride = a.geo.seg_stride();
+    const size_t my_base = (size_t)a.geo.seg * stride;
+    const double* __restrict__ xr = a.x;
+    for (uint32_t i = threadIdx.x; i < RB; i += 1024) acc_l[i] = 0.0;
+    double D = 0.0;
+    {
+        const uint32_t total = a.geo.n_seg * a.geo.nd_cap;
+        for (uint32_t t = lane; t < total; t += 64) {
+            uint32_t sg = t / a.geo.nd_cap, k = t - sg * a.geo.nd_cap;
+            D += xr[(size_t)sg * stride + a.geo.rows_cap + k];
+        }
+        D = wave_sum_f64(D);
+    }
+    const double dterm = D * a.inv_nm1;
+    __syncthreads();
+
+    const uint64_t e0 = a.bk_ptr[b], e1 = a.bk_ptr[b + 1];
+    constexpr int U = 4;
+    uint64_t e = e0 + threadIdx.x;
+    for (; e + (U - 1) * 1024 < e1; e += U * 1024) {
+        uint32_t c[U];
+        double w[U], xv[U];
+        uint32_t r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { c[u] = a.col[e + u * 1024]; w[u] = a.w[e + u * 1024]; r[u] = a.row[e + u * 1024]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = xr[(size_t)(c[u] >> COL_SEG_SHIFT) * stride + (c[u] & COL_LOCAL_MASK)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) atomicAdd(&acc_l[r[u]], w[u] * xv[u]);
+    }
+    for (; e < e1; e += 1024) {
+        uint32_t c = a.col[e];
+        double xv = xr[(size_t)(c >> COL_SEG_SHIFT) * stride + (c & COL_LOCAL_MASK)];
+        atomicAdd(&acc_l[a.row[e]], a.w[e] * xv);
+    }
+    __syncthreads();
+
+    double res = 0.0, tot = 0.0, dacc = 0.0;
+    const uint32_t n_groups = a.geo.rows_cap >> 6;
+    for (uint32_t lr = threadIdx.x; lr < RB; lr += 1024) {
+        const uint32_t grp = (lr >> 6) * B + b;
+        if (grp >= n_groups) continue;
+        const uint32_t row = grp * 64 + (lr & 63);
+        const uint64_t q = ((uint64_t)grp * a.geo.n_seg + a.geo.seg) * 64 + (lr & 63);
+        const bool active = q < a.geo.n_active;
+        const bool dang = q >= a.geo.n_active_pad && q < (uint64_t)a.geo.n_active_pad + a.geo.n_dangling;
+        if (!active && !dang) continue;
+        const double old = xr[my_base + row];
+        double v = dang ? acc_l[lr] + (D - old) * a.inv_nm1 : acc_l[lr] + dterm;
+        if (HAS_ALPHA) v = (1.0 - a.alpha) * v + a.alpha * a.pretrust[my_base + row];
+        a.y[my_base + row] = v;
+        res += fabs(v - old);
+        tot += v;
+        if (dang) dacc += v;
+    }
+    res = wave_sum_f64(res);
+    tot = wave_sum_f64(tot);
+    dacc = wave_sum_f64(dacc);
+    if (lane == 0) { red[0][wave] = res; red[1][wave] = tot; red[2][wave] = dacc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0, t = 0.0, d = 0.0;
+        for (int w = 0; w < 16; ++w) { r += red[0][w]; t += red[1][w]; d += red[2][w]; }
+        a.res_part[b] = r;
+        a.sum_part[b] = t;
+        a.y[my_base + a.geo.rows_cap + b] = d;   // partial sum slot b of this segment (nd_cap >= f64_blocks)
     }
 }
 
@@ -466,7 +571,7 @@ static int dev_upload(T** p, const std::vector<T>& v, uint64_t& total) {
 
 DeviceGraph::~DeviceGraph() {
     if (device >= 0) (void)hipSetDevice(device);
-    void* ptrs[] = {d_work, d_slices, d_col, d_w64, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
+    void* ptrs[] = {d_bk_ptr, d_bk_col, d_bk_row, d_bk_w, d_work, d_slices, d_col, d_w64, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
                     d_chg_part, d_stat_out, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* e : ev_begin) (void)hipEventDestroy((hipEvent_t)e);
@@ -515,17 +620,43 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     if (rc) { free_tmp(); return rc; }
     const unsigned nb = (unsigned)((slots + 255) / 256);
     if (g->variants & ET_VARIANT_F64) {
-        if ((rc = dev_upload(&d_scale64, h.scale_f64, tmp_bytes)) || (rc = dev_alloc(&g->d_w64, slots, tot))) { free_tmp(); return rc; }
-        if (slots) {
-            if (h.values_are_u32) hipLaunchKernelGGL(k_normalise_f64_u32, dim3(nb), dim3(256), 0, 0, g->d_col, d_val32, d_scale64, g->d_w64, slots, h.geo);
-            else hipLaunchKernelGGL(k_normalise_f64_fr, dim3(nb), dim3(256), 0, 0, g->d_col, d_valfr, d_scale64, g->d_w64, slots, h.geo);
+        g->f64_blocked = getenv("ET_F64_SELL") == nullptr;   // experiment switch: row-per-lane f64 kernel
+        g->n_f64_parts = g->f64_blocked ? h.geo.f64_blocks : g->n_work;
+        if ((rc = dev_upload(&d_scale64, h.scale_f64, tmp_bytes))) { free_tmp(); return rc; }
+        if (g->f64_blocked) {
+            const size_t ne = h.bk_col.size();
+            const unsigned nbe = (unsigned)((ne + 255) / 256);
+            if ((rc = dev_upload(&g->d_bk_ptr, h.bk_ptr, tot)) || (rc = dev_upload(&g->d_bk_col, h.bk_col, tot)) ||
+                (rc = dev_upload(&g->d_bk_row, h.bk_row, tot)) || (rc = dev_alloc(&g->d_bk_w, ne, tot))) { free_tmp(); return rc; }
+            if (ne) {
+                if (h.values_are_u32) {
+                    uint32_t* d_bv = nullptr;
+                    if ((rc = dev_upload(&d_bv, h.bk_val_u32, tmp_bytes))) { free_tmp(); return rc; }
+                    hipLaunchKernelGGL(k_normalise_f64_u32, dim3(nbe), dim3(256), 0, 0, g->d_bk_col, d_bv, d_scale64, g->d_bk_w, ne, h.geo);
+                    HIP_TRY(hipDeviceSynchronize());
+                    (void)hipFree(d_bv);
+                } else {
+                    uint4* d_bv = nullptr;
+                    if ((rc = dev_alloc(&d_bv, ne * 2, tmp_bytes))) { free_tmp(); return rc; }
+                    HIP_TRY(hipMemcpy(d_bv, h.bk_val_fr.data(), ne * 32, hipMemcpyHostToDevice));
+                    hipLaunchKernelGGL(k_normalise_f64_fr, dim3(nbe), dim3(256), 0, 0, g->d_bk_col, d_bv, d_scale64, g->d_bk_w, ne, h.geo);
+                    HIP_TRY(hipDeviceSynchronize());
+                    (void)hipFree(d_bv);
+                }
+            }
+        } else {
+            if ((rc = dev_alloc(&g->d_w64, slots, tot))) { free_tmp(); return rc; }
+            if (slots) {
+                if (h.values_are_u32) hipLaunchKernelGGL(k_normalise_f64_u32, dim3(nb), dim3(256), 0, 0, g->d_col, d_val32, d_scale64, g->d_w64, slots, h.geo);
+                else hipLaunchKernelGGL(k_normalise_f64_fr, dim3(nb), dim3(256), 0, 0, g->d_col, d_valfr, d_scale64, g->d_w64, slots, h.geo);
+            }
         }
         for (int i = 0; i < 2; ++i) {
             if ((rc = dev_alloc(&g->vx[i], vec_len, tot))) { free_tmp(); return rc; }
             HIP_TRY(hipMemset(g->vx[i], 0, vec_len * sizeof(double)));
         }
-        if ((rc = dev_alloc(&g->out_f64, h.n, tot)) || (rc = dev_alloc(&g->d_res_part, (size_t)STATS_RING * g->n_work, tot)) ||
-            (rc = dev_alloc(&g->d_sum_part, (size_t)STATS_RING * g->n_work, tot))) { free_tmp(); return rc; }
+        if ((rc = dev_alloc(&g->out_f64, h.n, tot)) || (rc = dev_alloc(&g->d_res_part, (size_t)STATS_RING * g->n_f64_parts, tot)) ||
+            (rc = dev_alloc(&g->d_sum_part, (size_t)STATS_RING * g->n_f64_parts, tot))) { free_tmp(); return rc; }
     }
     if (g->variants & ET_VARIANT_FR) {
         rc = dev_alloc(&d_scale_fr, vec_len * 2, tmp_bytes);
@@ -547,6 +678,8 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     HIP_TRY(hipFuncSetAttribute((const void*)k_step_f64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute((const void*)k_step_f64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     HIP_TRY(hipFuncSetAttribute((const void*)k_step_fr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_step_f64_blocked<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_step_f64_blocked<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     free_tmp();
@@ -574,20 +707,28 @@ int DeviceGraph::init_fr(uint64_t lo, uint64_t hi, uint4* x, hipStream_t st) {
 int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, hipStream_t st) {
     if (!(variants & ET_VARIANT_F64)) { set_error("graph was built without the f64 variant"); return ET_E_UNSUPPORTED; }
     if (x == y) { set_error("step needs distinct input and output vectors"); return ET_E_INVALID_ARG; }
+    if (alpha != 0.0 && !pretrust) { set_error("alpha != 0 needs a pre-trust vector"); return ET_E_INVALID_ARG; }
+    const size_t ring = (size_t)(iteration % STATS_RING) * n_f64_parts;
+    if (f64_blocked) {
+        StepArgsF64B a;
+        a.bk_ptr = d_bk_ptr; a.col = d_bk_col; a.w = d_bk_w; a.row = d_bk_row; a.x = x; a.y = y; a.pretrust = pretrust;
+        a.res_part = d_res_part + ring; a.sum_part = d_sum_part + ring;
+        a.geo = geo; a.inv_nm1 = inv_nm1; a.alpha = alpha;
+        const size_t lds = (size_t)geo.f64_rb * sizeof(double);
+        if (alpha != 0.0) hipLaunchKernelGGL(k_step_f64_blocked<true>, dim3(geo.f64_blocks), dim3(1024), lds, st, a);
+        else hipLaunchKernelGGL(k_step_f64_blocked<false>, dim3(geo.f64_blocks), dim3(1024), lds, st, a);
+        HIP_TRY(hipGetLastError());
+        return ET_OK;
+    }
     StepArgsF64 a;
     a.work = d_work; a.slices = d_slices; a.col = d_col; a.w = d_w64; a.x = x; a.y = y; a.pretrust = pretrust;
-    size_t ring = (size_t)(iteration % STATS_RING) * n_work;
     a.res_part = d_res_part + ring; a.sum_part = d_sum_part + ring;
     a.geo = geo; a.n_work = n_work; a.inv_nm1 = inv_nm1; a.alpha = alpha;
     if (n_work == 0) return ET_OK;
     const unsigned grid = (n_work + WPB_F64 - 1) / WPB_F64;
     const size_t lds = (size_t)geo.n_seg * geo.hot_f64 * sizeof(double);
-    if (alpha != 0.0) {
-        if (!pretrust) { set_error("alpha != 0 needs a pre-trust vector"); return ET_E_INVALID_ARG; }
-        hipLaunchKernelGGL(k_step_f64<true>, dim3(grid), dim3(WPB_F64 * 64), lds, st, a);
-    } else {
-        hipLaunchKernelGGL(k_step_f64<false>, dim3(grid), dim3(WPB_F64 * 64), lds, st, a);
-    }
+    if (alpha != 0.0) hipLaunchKernelGGL(k_step_f64<true>, dim3(grid), dim3(WPB_F64 * 64), lds, st, a);
+    else hipLaunchKernelGGL(k_step_f64<false>, dim3(grid), dim3(WPB_F64 * 64), lds, st, a);
     HIP_TRY(hipGetLastError());
     return ET_OK;
 }
@@ -618,9 +759,9 @@ int DeviceGraph::unpermute_fr(const uint4* x, uint4* out, hipStream_t st) {
 }
 int DeviceGraph::stats_f64(uint32_t iteration, hipStream_t st, et_iter_stats* out) {
     if (!(variants & ET_VARIANT_F64)) return ET_E_UNSUPPORTED;
-    size_t ring = (size_t)(iteration % STATS_RING) * n_work;
+    size_t ring = (size_t)(iteration % STATS_RING) * n_f64_parts;
     double* o = (double*)d_stat_out;
-    hipLaunchKernelGGL(k_stats_f64, dim3(1), dim3(64), 0, st, d_res_part + ring, d_sum_part + ring, n_work, o);
+    hipLaunchKernelGGL(k_stats_f64, dim3(1), dim3(64), 0, st, d_res_part + ring, d_sum_part + ring, n_f64_parts, o);
     HIP_TRY(hipGetLastError());
     double h[2];
     HIP_TRY(hipMemcpyAsync(h, o, sizeof(h), hipMemcpyDeviceToHost, st));

@@ -33,6 +33,12 @@ struct DeviceGraph {
     SliceDesc* d_slices = nullptr;
     uint32_t* d_col = nullptr;
     double* d_w64 = nullptr;
+    bool f64_blocked = true;
+    uint32_t n_f64_parts = 0;
+    uint64_t* d_bk_ptr = nullptr;
+    uint32_t* d_bk_col = nullptr;
+    uint16_t* d_bk_row = nullptr;
+    double* d_bk_w = nullptr;
     uint4* d_wlo = nullptr;
     uint4* d_whi = nullptr;
     uint32_t* d_pos = nullptr;

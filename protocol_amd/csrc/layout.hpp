@@ -61,6 +61,9 @@ struct Geometry {
     // The first hot_* local rows of every segment hold the most frequently gathered sources; the
     // step kernels keep them in LDS (per variant, because the entry size differs).
     uint32_t hot_f64, hot_fr;
+    // f64 variant: the segment's 64-row groups are dealt round-robin to f64_blocks workgroups, each
+    // of which keeps f64_rb row accumulators in LDS and walks its edges in ascending source order.
+    uint32_t f64_blocks, f64_rb;
     ET_HD uint32_t seg_stride() const { return rows_cap + nd_cap; }
     ET_HD uint32_t pos_of_col(uint32_t c) const { return (c >> COL_SEG_SHIFT) * seg_stride() + (c & COL_LOCAL_MASK); }
 };
