@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstring>
 #include <numeric>
+#include <queue>
 
 #include "../../include/eigentrust_hip.h"
 
@@ -172,11 +173,15 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     geo.hot_fr = std::min<uint32_t>(geo.rows_cap, (opt.hot_fr / G) / 64 * 64);
     {
         // f64 workgroups: one per CU unless the rows of a workgroup would not fit its LDS accumulators
-        const uint32_t n_groups = geo.rows_cap / 64, rb_max = 16384;
+        // (12288 rows plus the slack below stay under 160 KiB of f64 accumulators)
+        const uint32_t n_groups = geo.rows_cap / 64, rb_max = 12288;
         uint32_t B = std::max<uint32_t>(1, std::min<uint32_t>(opt.f64_blocks ? opt.f64_blocks : 256, n_groups));
         B = std::max<uint32_t>(B, (geo.rows_cap + rb_max - 1) / rb_max);
         geo.f64_blocks = B;
-        geo.f64_rb = std::max<uint32_t>(64, (n_groups + B - 1) / B * 64);
+        // a quarter more accumulator slots than an even deal needs: workgroups holding light rows
+        // take more 64-row groups than those holding heavy ones
+        const uint32_t even = (n_groups + B - 1) / B;
+        geo.f64_rb = (even + even / 4 + 2) * 64;
         geo.nd_cap = std::max<uint32_t>(geo.nd_cap, (B + 15) / 16 * 16);
     }
     g.geo = geo;
@@ -232,10 +237,34 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     g.nnz_local = in_ptr[geo.rows_cap];
     std::vector<uint32_t> e_src(g.nnz_local);   // source, encoded (segment << 29) | local row
     std::vector<uint64_t> e_idx(g.nnz_local);   // original edge index (for the value)
-    // the same edges grouped by f64 workgroup (64-row groups dealt round-robin), ascending by source
-    const uint32_t B = geo.f64_blocks;
+    // the same edges grouped by f64 workgroup, ascending by source.  The 64-row groups are handed
+    // out heaviest first, each to the workgroup with the fewest edges so far that still has a free
+    // accumulator slot: the launch ends with its slowest workgroup, so edge counts must be level.
+    const uint32_t B = geo.f64_blocks, gpb = geo.f64_rb / 64, n_groups = geo.rows_cap / 64;
+    g.bk_grp.assign((size_t)B * gpb, 0xFFFFFFFFu);
+    std::vector<uint32_t> grp_block(n_groups), grp_slot(n_groups);
     g.bk_ptr.assign((size_t)B + 1, 0);
-    for (uint32_t lr = 0; lr < geo.rows_cap; ++lr) g.bk_ptr[(lr >> 6) % B + 1] += in_ptr[lr + 1] - in_ptr[lr];
+    {
+        std::vector<uint64_t> grp_edges(n_groups);
+        for (uint32_t gi = 0; gi < n_groups; ++gi) grp_edges[gi] = in_ptr[(size_t)gi * 64 + 64] - in_ptr[(size_t)gi * 64];
+        std::vector<uint32_t> by_weight(n_groups);
+        std::iota(by_weight.begin(), by_weight.end(), 0u);
+        std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t a, uint32_t b) { return grp_edges[a] > grp_edges[b]; });
+        typedef std::pair<uint64_t, uint32_t> Load;   // (edges so far, workgroup)
+        std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+        for (uint32_t b = 0; b < B; ++b) heap.push(Load(0, b));
+        std::vector<uint32_t> used(B, 0);
+        for (uint32_t gi : by_weight) {
+            Load l = heap.top();
+            heap.pop();
+            const uint32_t b = l.second;
+            grp_block[gi] = b;
+            grp_slot[gi] = used[b];
+            g.bk_grp[(size_t)b * gpb + used[b]] = gi;
+            g.bk_ptr[b + 1] += grp_edges[gi];
+            if (++used[b] < gpb) heap.push(Load(l.first + grp_edges[gi], b));   // a full workgroup leaves the heap
+        }
+    }
     for (uint32_t b = 0; b < B; ++b) g.bk_ptr[b + 1] += g.bk_ptr[b];
     g.bk_col.resize(g.nnz_local);
     g.bk_row.resize(g.nnz_local);
@@ -259,9 +288,9 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
                 e_src[p] = pf;
                 e_idx[p] = kept[k];
                 const uint32_t grp = lr >> 6;
-                uint64_t q = bcur[grp % B]++;
+                uint64_t q = bcur[grp_block[grp]]++;
                 g.bk_col[q] = pf;
-                g.bk_row[q] = (uint16_t)((grp / B) * 64 + (lr & 63));
+                g.bk_row[q] = (uint16_t)(grp_slot[grp] * 64 + (lr & 63));
                 if (g.values_are_u32) g.bk_val_u32[q] = in.val_u32[kept[k]];
                 else g.bk_val_fr[q] = in.val_fr[kept[k]];
             }

@@ -237,8 +237,8 @@ __global__ __launch_bounds__(WPB_F64 * 64) void k_step_f64(StepArgsF64 a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// f64 variant, "blocked sweep".  One 1024-thread workgroup per CU owns geo.f64_rb rows (64-row
-// groups dealt round-robin, so every workgroup gets the same degree mix) with their accumulators in
+// f64 variant, "blocked sweep".  One 1024-thread workgroup per CU owns up to geo.f64_rb rows (64-row
+// groups handed out so that every workgroup gets the same number of edges) with their accumulators in
 // LDS, and walks its edges in ascending SOURCE order: the edge records stream in coalesced, each
 // edge costs one 8-byte gather and one LDS atomic add.  Because every workgroup sweeps the source
 // range at the same pace, the part of the trust vector being gathered at any moment is a narrow
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(WPB_F64 * 64) void k_step_f64(StepArgsF64 a) {
 // ---------------------------------------------------------------------------------------------
 struct StepArgsF64B {
     const uint64_t* bk_ptr;
+    const uint32_t* grp;      // [f64_blocks][f64_rb / 64] 64-row group behind each accumulator slot, ~0 = none
     const uint32_t* col;
     const double* w;
     const uint16_t* row;
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x;
-    const uint32_t B = a.geo.f64_blocks, RB = a.geo.f64_rb;
+    const uint32_t RB = a.geo.f64_rb;
     const uint32_t stride = a.geo.seg_stride();
     const size_t my_base = (size_t)a.geo.seg * stride;
     const double* __restrict__ xr = a.x;
@@ -309,10 +310,9 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     __syncthreads();
 
     double res = 0.0, tot = 0.0, dacc = 0.0;
-    const uint32_t n_groups = a.geo.rows_cap >> 6;
     for (uint32_t lr = threadIdx.x; lr < RB; lr += 1024) {
-        const uint32_t grp = (lr >> 6) * B + b;
-        if (grp >= n_groups) continue;
+        const uint32_t grp = a.grp[(size_t)b * (RB >> 6) + (lr >> 6)];
+        if (grp == 0xFFFFFFFFu) continue;
         const uint32_t row = grp * 64 + (lr & 63);
         const uint64_t q = ((uint64_t)grp * a.geo.n_seg + a.geo.seg) * 64 + (lr & 63);
         const bool active = q < a.geo.n_active;
@@ -571,7 +571,7 @@ static int dev_upload(T** p, const std::vector<T>& v, uint64_t& total) {
 
 DeviceGraph::~DeviceGraph() {
     if (device >= 0) (void)hipSetDevice(device);
-    void* ptrs[] = {d_bk_ptr, d_bk_col, d_bk_row, d_bk_w, d_work, d_slices, d_col, d_w64, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
+    void* ptrs[] = {d_bk_ptr, d_bk_grp, d_bk_col, d_bk_row, d_bk_w, d_work, d_slices, d_col, d_w64, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
                     d_chg_part, d_stat_out, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* e : ev_begin) (void)hipEventDestroy((hipEvent_t)e);
@@ -626,7 +626,7 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
         if (g->f64_blocked) {
             const size_t ne = h.bk_col.size();
             const unsigned nbe = (unsigned)((ne + 255) / 256);
-            if ((rc = dev_upload(&g->d_bk_ptr, h.bk_ptr, tot)) || (rc = dev_upload(&g->d_bk_col, h.bk_col, tot)) ||
+            if ((rc = dev_upload(&g->d_bk_ptr, h.bk_ptr, tot)) || (rc = dev_upload(&g->d_bk_grp, h.bk_grp, tot)) || (rc = dev_upload(&g->d_bk_col, h.bk_col, tot)) ||
                 (rc = dev_upload(&g->d_bk_row, h.bk_row, tot)) || (rc = dev_alloc(&g->d_bk_w, ne, tot))) { free_tmp(); return rc; }
             if (ne) {
                 if (h.values_are_u32) {
@@ -711,7 +711,7 @@ int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double
     const size_t ring = (size_t)(iteration % STATS_RING) * n_f64_parts;
     if (f64_blocked) {
         StepArgsF64B a;
-        a.bk_ptr = d_bk_ptr; a.col = d_bk_col; a.w = d_bk_w; a.row = d_bk_row; a.x = x; a.y = y; a.pretrust = pretrust;
+        a.bk_ptr = d_bk_ptr; a.grp = d_bk_grp; a.col = d_bk_col; a.w = d_bk_w; a.row = d_bk_row; a.x = x; a.y = y; a.pretrust = pretrust;
         a.res_part = d_res_part + ring; a.sum_part = d_sum_part + ring;
         a.geo = geo; a.inv_nm1 = inv_nm1; a.alpha = alpha;
         const size_t lds = (size_t)geo.f64_rb * sizeof(double);

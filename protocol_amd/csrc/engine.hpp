@@ -36,6 +36,7 @@ struct DeviceGraph {
     bool f64_blocked = true;
     uint32_t n_f64_parts = 0;
     uint64_t* d_bk_ptr = nullptr;
+    uint32_t* d_bk_grp = nullptr;
     uint32_t* d_bk_col = nullptr;
     uint16_t* d_bk_row = nullptr;
     double* d_bk_w = nullptr;
