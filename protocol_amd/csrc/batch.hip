@@ -189,6 +189,208 @@ __global__ __launch_bounds__(BATCH_THREADS) void k_batch_fr(BatchArgs a) {
     }
 }
 
+// Byte-valued opinions (the production range): the accumulation runs on 16-bit limbs.
+// xs_j is the same for every lane of a wavefront (the lanes differ in the column i), so its eight
+// words are moved to scalar registers once per j; limb (16 bit) x opinion (8 bit) < 2^24 is a
+// full-rate 24-bit multiply-add into sixteen 32-bit column sums with no carry handling, and the
+// column sums are folded into the 320-bit accumulator every 256 products (256 * 2^24 = 2^32).
+// A column's j range is split over `parts` threads in different wavefronts, so that each SIMD has
+// several wavefronts to switch between; the partial accumulators meet in LDS.  Integer addition
+// is associative, so neither the limb width nor the split can change a bit of the result.
+struct BatchArgsU8 {
+    BatchArgs b;
+    uint32_t cols;    // n rounded up to a multiple of 64
+    uint32_t parts;   // threads per column; blockDim.x == cols * parts
+};
+
+ET_DEV void acc10_fold(Acc10& acc, uint32_t (&cs)[16]) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        c += (uint64_t)acc.v[q] + cs[2 * q] + ((uint64_t)cs[2 * q + 1] << 16);
+        acc.v[q] = (uint32_t)c;
+        c >>= 32;
+        cs[2 * q] = 0;
+        cs[2 * q + 1] = 0;
+    }
+    c += acc.v[8];
+    acc.v[8] = (uint32_t)c;
+    acc.v[9] += (uint32_t)(c >> 32);
+}
+
+template <bool VALS_IN_LDS>
+__global__ __launch_bounds__(1024) void k_batch_fr_u8(BatchArgsU8 au) {
+    const BatchArgs& a = au.b;
+    extern __shared__ uint4 lds4[];
+    const uint32_t n = a.n, cols = au.cols, parts = au.parts;
+    // LDS carve-up: s[n], next s[n], xs[n] (2 x uint4 each), 16 reduction slots, partial
+    // accumulators [10][parts - 1][n], optional opinion matrix
+    uint4* s_l = lds4;
+    uint4* sn_l = lds4 + 2 * (size_t)n;
+    uint4* xs_l = lds4 + 4 * (size_t)n;
+    uint4* red_l = lds4 + 6 * (size_t)n;
+    uint32_t* part_l = reinterpret_cast<uint32_t*>(red_l + 2 * 16 + 2);
+    uint8_t* v_l = reinterpret_cast<uint8_t*>(part_l + (size_t)10 * (parts - 1) * n);
+    __shared__ uint32_t sh_D[8];
+    __shared__ uint32_t sh_nv[16];
+    const uint32_t set = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const uint8_t* vg = reinterpret_cast<const uint8_t*>(a.vals) + (size_t)set * n * n;
+    const uint8_t* mem = a.member + (size_t)set * n;
+    const uint8_t* dng = a.dangling + (size_t)set * n;
+    uint4* outp = a.out + 2 * (size_t)set * n;
+
+    if (a.pre_status[set] != ET_OK) {
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) u256_store(outp + 2 * i, u256_zero());
+        if (threadIdx.x == 0) a.status[set] = a.pre_status[set];
+        return;
+    }
+    if (VALS_IN_LDS) {
+        // n * n bytes; the carve-up above keeps v_l 16-byte aligned when n is a multiple of 4
+        const size_t total = (size_t)n * n;
+        if ((n & 3) == 0) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(vg);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(v_l);
+            for (size_t t = threadIdx.x; t < total / 4; t += blockDim.x) dst[t] = src[t];
+        } else {
+            for (size_t t = threadIdx.x; t < total; t += blockDim.x) v_l[t] = vg[t];
+        }
+    }
+    const uint8_t* vsrc = VALS_IN_LDS ? v_l : vg;
+    const U256 inw = u256_load(a.inv_nm1_w + 2 * (size_t)set);
+    uint32_t n_valid_local = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        u256_store(s_l + 2 * i, mem[i] ? a.initial : u256_zero());   // native.rs:317
+        n_valid_local += mem[i] != 0;
+    }
+    __syncthreads();
+
+    const uint32_t part = threadIdx.x / cols, i = threadIdx.x - part * cols;
+    const uint32_t ii = i < n ? i : n - 1;                    // lanes past the last column compute and discard
+    const uint32_t j_lo = (uint32_t)((uint64_t)part * n / parts), j_hi = (uint32_t)((uint64_t)(part + 1) * n / parts);
+    const bool is_member = i < n && mem[ii] != 0;
+    const bool is_dangling = i < n && dng[ii] != 0;
+
+    for (uint32_t it = 0; it < a.num_iter; ++it) {
+        // phase 1: xs_j = s_j * inv(sum_j) * 2^288, and the score mass of dangling peers
+        U256 dpart = u256_zero();
+        for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+            U256 sk = u256_load(s_l + 2 * k);
+            U256 f = u256_load(a.scale + 2 * ((size_t)set * n + k));
+            Acc t = acc_zero();
+            acc_mac(t, sk, f);
+            u256_store(xs_l + 2 * k, acc_redc288(t));
+            if (dng[k]) dpart = fr_add(dpart, sk);
+        }
+        if ((uint32_t)wave * 64 < n) {                        // the other wavefronts hold no element of s
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                U256 o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o.v[q] = __shfl_xor(dpart.v[q], off, 64);
+                dpart = fr_add(dpart, o);
+            }
+            if (lane == 0) u256_store(red_l + 2 * wave, dpart);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            U256 d = u256_zero();
+            for (uint32_t w = 0; w * 64 < n; ++w) d = fr_add(d, u256_load(red_l + 2 * w));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sh_D[q] = d.v[q];
+        }
+        __syncthreads();
+
+        // phase 2: new_s_i = sum_j v_ji * xs_j + (D - dangling_i * s_i) * inv(n_valid-1).
+        // The host zeroed the diagonal and every opinion from or about an empty slot
+        // (native.rs:241-259), so the loop has no conditions.
+        Acc10 acc;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) acc.v[q] = 0;
+        uint32_t cs[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) cs[q] = 0;
+        for (uint32_t j0 = j_lo; j0 < j_hi; j0 += 256) {
+            const uint32_t j1 = j0 + 256 < j_hi ? j0 + 256 : j_hi;
+            uint32_t idx = j0 * n + ii;                       // n <= 1024: fits 32 bits
+            for (uint32_t j = j0; j < j1; ++j, idx += n) {
+                const uint32_t op = vsrc[idx];
+                const uint4 x0 = xs_l[2 * j], x1 = xs_l[2 * j + 1];
+                const uint32_t xw[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t u = __builtin_amdgcn_readfirstlane(xw[q]);
+                    cs[2 * q] += __umul24(u & 0xFFFFu, op);
+                    cs[2 * q + 1] += __umul24(u >> 16, op);
+                }
+            }
+            acc10_fold(acc, cs);
+        }
+        if (part > 0 && i < n) {
+#pragma unroll
+            for (int q = 0; q < 10; ++q) part_l[((size_t)q * (parts - 1) + (part - 1)) * n + i] = acc.v[q];
+        }
+        __syncthreads();
+        if (part == 0 && i < n) {
+            U256 v = u256_zero();
+            if (is_member) {
+                for (uint32_t p = 0; p + 1 < parts; ++p) {
+                    uint64_t c = 0;
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) {
+                        c += (uint64_t)acc.v[q] + part_l[((size_t)q * (parts - 1) + p) * n + i];
+                        acc.v[q] = (uint32_t)c;
+                        c >>= 32;
+                    }
+                }
+                Acc full = acc_zero();
+#pragma unroll
+                for (int q = 0; q < 10; ++q) full.v[q] = acc.v[q];
+                U256 D;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) D.v[q] = sh_D[q];
+                U256 t = is_dangling ? fr_sub(D, u256_load(s_l + 2 * i)) : D;
+                acc_mac(full, inw, t);
+                v = acc_redc288(full);
+            }
+            u256_store(sn_l + 2 * i, v);
+        }
+        __syncthreads();
+        uint4* tmp = s_l; s_l = sn_l; sn_l = tmp;
+    }
+    // output + conservation check (native.rs:331-334): sum of scores == INITIAL * n_valid
+    U256 tot = u256_zero();
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+        U256 sk = u256_load(s_l + 2 * k);
+        u256_store(outp + 2 * k, sk);
+        tot = fr_add(tot, sk);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        U256 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o.v[q] = __shfl_xor(tot.v[q], off, 64);
+        tot = fr_add(tot, o);
+        n_valid_local += __shfl_xor(n_valid_local, off, 64);
+    }
+    if (lane == 0) { u256_store(red_l + 2 * wave, tot); sh_nv[wave] = n_valid_local; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        U256 t = u256_zero();
+        uint32_t nv = 0;
+        for (int w = 0; w < n_waves; ++w) { t = fr_add(t, u256_load(red_l + 2 * w)); nv += sh_nv[w]; }
+        U256 expect = u256_zero();
+        for (uint32_t k = 0; k < nv; ++k) expect = fr_add(expect, a.initial);   // nv <= 1024
+        a.status[set] = u256_eq(t, expect) ? ET_OK : ET_E_SUM_MISMATCH;
+    }
+}
+
+static size_t batch_u8_lds_bytes(uint32_t n, uint32_t parts, bool vals_in_lds) {
+    size_t b = (6 * (size_t)n + 2 * 16 + 2) * sizeof(uint4) + (size_t)40 * (parts - 1) * n;
+    if (vals_in_lds) b += (size_t)n * n;
+    return b;
+}
+
 struct DeviceBatch {
     int device = -1;
     uint32_t n_sets = 0, n = 0;
@@ -336,13 +538,24 @@ int et_batch_run_fr_async(et_batch* h, uint32_t num_iterations, uint64_t initial
     const size_t budget = 150 * 1024;
     hipStream_t st = (hipStream_t)stream;
     if (b.vals_u8) {
-        bool in_lds = batch_lds_bytes(b.n, true, 1) <= budget;
-        size_t lds = batch_lds_bytes(b.n, in_lds, 1);
+        BatchArgsU8 au;
+        au.b = a;
+        au.cols = (b.n + 63) / 64 * 64;
+        au.parts = std::max(1u, std::min(1024u / au.cols, b.n / 32));
+        bool in_lds = true;
+        if (batch_u8_lds_bytes(b.n, au.parts, true) > budget) {
+            // prefer the resident opinion matrix over the split when both do not fit
+            if (batch_u8_lds_bytes(b.n, 1, true) <= budget) au.parts = 1;
+            else in_lds = false;
+        }
+        const size_t lds = batch_u8_lds_bytes(b.n, au.parts, in_lds);
+        const dim3 block(au.cols * au.parts);
         if (in_lds) {
-            HIP_TRY_B(hipFuncSetAttribute((const void*)k_batch_fr<uint8_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget));
-            hipLaunchKernelGGL((k_batch_fr<uint8_t, true>), dim3(b.n_sets), dim3(BATCH_THREADS), lds, st, a);
+            HIP_TRY_B(hipFuncSetAttribute((const void*)k_batch_fr_u8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget));
+            hipLaunchKernelGGL((k_batch_fr_u8<true>), dim3(b.n_sets), block, lds, st, au);
         } else {
-            hipLaunchKernelGGL((k_batch_fr<uint8_t, false>), dim3(b.n_sets), dim3(BATCH_THREADS), lds, st, a);
+            HIP_TRY_B(hipFuncSetAttribute((const void*)k_batch_fr_u8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget));
+            hipLaunchKernelGGL((k_batch_fr_u8<false>), dim3(b.n_sets), block, lds, st, au);
         }
     } else {
         bool in_lds = batch_lds_bytes(b.n, true, 4) <= budget;

@@ -16,7 +16,9 @@ def dense_expect(values, member, iters, initial):
 
 
 @pytest.mark.parametrize("n,n_sets,vmax", [(4, 9, 255), (12, 5, 1000), (64, 6, 255), (256, 8, 255), (256, 3, 2**32 - 1),
-                                          (300, 2, 255), (700, 1, 70000)])
+                                          (300, 2, 255), (700, 1, 70000),
+                                          # byte-valued kernel: uneven column split, matrix left in global memory, >256 sources per part
+                                          (33, 4, 3), (100, 3, 255), (130, 2, 200), (400, 2, 255), (1000, 1, 255)])
 def test_batch_matches_dense_restatement(n, n_sets, vmax):
     rng = np.random.default_rng(n * 7 + n_sets)
     values = rng.integers(0, vmax + 1, (n_sets, n, n), dtype=np.uint64).astype(np.uint32)

@@ -7,6 +7,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+wanted = sys.argv[2] if len(sys.argv) > 2 else "k_step"   # substring of the kernel names to report
 acc = defaultdict(lambda: [0.0, 0])
 for path in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
     with open(path) as f:
@@ -17,7 +18,7 @@ for path in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv
             acc[key][1] += 1
 kernels = sorted({k[0] for k in acc})
 for kn in kernels:
-    if "k_step" not in kn:
+    if wanted not in kn:
         continue
     print(kn)
     for (name, ctr), (tot, cnt) in sorted(acc.items()):
