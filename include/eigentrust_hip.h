@@ -188,15 +188,27 @@ int et_graph_converge_f64(et_graph *g, uint32_t num_iterations, double initial, 
  * calls only enqueue work and allocate nothing. */
 
 /* Writes this share's segment of the initial vector (INITIAL_SCORE for members, native.rs:184,317)
- * plus its partial sums into x; other segments are left untouched (all-gather them). */
-int et_graph_init_fr_async(et_graph *g, uint64_t initial_lo, uint64_t initial_hi, void *x, void *stream);
-int et_graph_init_f64_async(et_graph *g, double initial, void *x, void *stream);
+ * plus its partial sums into x; other segments are left untouched (all-gather them).  Without
+ * ET_INIT_PLAIN the vector is in the form the steps exchange (see et_graph_step_*). */
+#define ET_INIT_PLAIN 1u   /* write plain scores: a pre-trust vector, or a converge of zero iterations */
+int et_graph_init_fr_async(et_graph *g, uint64_t initial_lo, uint64_t initial_hi, void *x,
+                           uint32_t flags, void *stream);
+int et_graph_init_f64_async(et_graph *g, double initial, void *x, uint32_t flags, void *stream);
 /* One iteration (native.rs:320-328 for every row of this share): reads all of x, writes this
  * share's segment of y.  `iteration` selects the slot of the per-iteration statistics.
- * pretrust_pos: device doubles in position order, or NULL. */
-int et_graph_step_fr_async(et_graph *g, const void *x, void *y, uint32_t iteration, void *stream);
+ * pretrust_pos: device doubles in position order, or NULL.
+ *
+ * When the opinions are integers the weights c_ji = v_ji * inv(sum_j) (native.rs:305-314) are
+ * never stored: between iterations the vectors hold s_j * inv(sum_j), the edge records hold v_ji,
+ * and the plain scores of the share's own rows are kept inside the graph object (so one graph
+ * serves one converge at a time).  The LAST step of a converge must carry ET_STEP_FINAL: its
+ * output holds plain scores and is the only one et_graph_unpermute_* may be given.  A vector
+ * written by et_graph_init_* must go through at least one step before it is read back. */
+#define ET_STEP_FINAL 1u
+int et_graph_step_fr_async(et_graph *g, const void *x, void *y, uint32_t iteration, uint32_t flags,
+                           void *stream);
 int et_graph_step_f64_async(et_graph *g, const void *x, void *y, uint32_t iteration, double alpha,
-                            const void *pretrust_pos, void *stream);
+                            const void *pretrust_pos, uint32_t flags, void *stream);
 /* Position order -> slot order (device to device): out has n entries. */
 int et_graph_unpermute_fr_async(et_graph *g, const void *x, void *out_slots, void *stream);
 int et_graph_unpermute_f64_async(et_graph *g, const void *x, void *out_slots, void *stream);

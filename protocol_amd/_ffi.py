@@ -70,6 +70,9 @@ class EtIterStats(C.Structure):
 # every symbol include/eigentrust_hip.h declares, with its prototype
 vp, u32, u64, i32, dbl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
 P = C.POINTER
+ET_STEP_FINAL = 1
+ET_INIT_PLAIN = 1
+
 PROTOTYPES = {
     "et_strerror": (C.c_char_p, [i32]),
     "et_last_error_message": (C.c_char_p, []),
@@ -96,10 +99,10 @@ PROTOTYPES = {
     "et_graph_info_get": (i32, [vp, P(EtGraphInfo)]),
     "et_graph_converge_fr": (i32, [vp, u32, u64, u64, vp]),
     "et_graph_converge_f64": (i32, [vp, u32, dbl, dbl, vp, vp, P(dbl)]),
-    "et_graph_init_fr_async": (i32, [vp, u64, u64, vp, vp]),
-    "et_graph_init_f64_async": (i32, [vp, dbl, vp, vp]),
-    "et_graph_step_fr_async": (i32, [vp, vp, vp, u32, vp]),
-    "et_graph_step_f64_async": (i32, [vp, vp, vp, u32, dbl, vp, vp]),
+    "et_graph_init_fr_async": (i32, [vp, u64, u64, vp, u32, vp]),
+    "et_graph_init_f64_async": (i32, [vp, dbl, vp, u32, vp]),
+    "et_graph_step_fr_async": (i32, [vp, vp, vp, u32, u32, vp]),
+    "et_graph_step_f64_async": (i32, [vp, vp, vp, u32, dbl, vp, u32, vp]),
     "et_graph_unpermute_fr_async": (i32, [vp, vp, vp, vp]),
     "et_graph_unpermute_f64_async": (i32, [vp, vp, vp, vp]),
     "et_graph_permute_f64_host": (i32, [vp, vp, vp]),

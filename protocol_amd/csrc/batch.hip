@@ -38,23 +38,6 @@ namespace et {
 
 static const int BATCH_THREADS = 256;
 
-// 320-bit accumulator for sums of (32-bit opinion) x (field element): holds 2^34 such products
-struct Acc10 {
-    uint32_t v[10];
-};
-ET_DEV void acc10_mac_u32(Acc10& acc, const U256& a, uint32_t v) {
-    uint64_t c = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        uint64_t t = (uint64_t)a.v[j] * v + acc.v[j] + c;
-        acc.v[j] = (uint32_t)t;
-        c = t >> 32;
-    }
-    uint64_t t = (uint64_t)acc.v[8] + c;
-    acc.v[8] = (uint32_t)t;
-    acc.v[9] += (uint32_t)(t >> 32);
-}
-
 struct BatchArgs {
     const void* vals;        // n_sets * n * n opinions, row-major (row = attester), uint8 or uint32
     const uint8_t* member;   // n_sets * n

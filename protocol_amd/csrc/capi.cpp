@@ -70,11 +70,9 @@ static void read_opts(const et_build_opts* opts, BuildOpts& bo, int& variants, i
     device = opts->device;
 }
 
-// Tuning knobs for experiments (not part of the ABI): ET_TARGET_WORK, ET_HOT_F64, ET_HOT_FR, ET_LONG_ROW.
+// Tuning knobs for experiments (not part of the ABI): ET_TARGET_WORK, ET_LONG_ROW, ET_F64_BLOCKS.
 static void read_env(BuildOpts& bo) {
     if (const char* e = getenv("ET_TARGET_WORK")) bo.target_work = (uint32_t)atoi(e);
-    if (const char* e = getenv("ET_HOT_F64")) bo.hot_f64 = (uint32_t)atoi(e);
-    if (const char* e = getenv("ET_HOT_FR")) bo.hot_fr = (uint32_t)atoi(e);
     if (const char* e = getenv("ET_LONG_ROW")) bo.long_row = (uint32_t)atoi(e);
     if (const char* e = getenv("ET_F64_BLOCKS")) bo.f64_blocks = (uint32_t)atoi(e);
 }
@@ -205,9 +203,10 @@ int et_graph_converge_f64(et_graph* g, uint32_t num_iterations, double initial, 
             d->device_bytes += d->vec_len * sizeof(double);
         }
         HIP_TRY_C(hipMemcpy(d->d_pretrust, pos.data(), d->vec_len * sizeof(double), hipMemcpyHostToDevice));
-        if ((rc = d->init_f64(initial, d->vx[0], nullptr))) return rc;
+        if ((rc = d->init_f64(initial, d->vx[0], nullptr, num_iterations == 0))) return rc;
         for (uint32_t it = 0; it < num_iterations; ++it)
-            if ((rc = d->step_f64(d->vx[it & 1], d->vx[(it + 1) & 1], it, alpha, d->d_pretrust, nullptr))) return rc;
+            if ((rc = d->step_f64(d->vx[it & 1], d->vx[(it + 1) & 1], it, alpha, d->d_pretrust,
+                                  it + 1 == num_iterations ? ET_STEP_FINAL : 0u, nullptr))) return rc;
         if ((rc = d->unpermute_f64(d->vx[num_iterations & 1], d->out_f64, nullptr))) return rc;
     } else {
         if ((rc = d->run_f64(num_iterations, initial, alpha, nullptr, false))) return rc;
@@ -224,22 +223,22 @@ int et_graph_converge_f64(et_graph* g, uint32_t num_iterations, double initial, 
     return ET_OK;
 }
 
-int et_graph_init_fr_async(et_graph* g, uint64_t lo, uint64_t hi, void* x, void* stream) {
+int et_graph_init_fr_async(et_graph* g, uint64_t lo, uint64_t hi, void* x, uint32_t flags, void* stream) {
     if (!g || !x) return ET_E_INVALID_ARG;
-    return G(g)->init_fr(lo, hi, (uint4*)x, (hipStream_t)stream);
+    return G(g)->init_fr(lo, hi, (uint4*)x, (hipStream_t)stream, (flags & ET_INIT_PLAIN) != 0);
 }
-int et_graph_init_f64_async(et_graph* g, double initial, void* x, void* stream) {
+int et_graph_init_f64_async(et_graph* g, double initial, void* x, uint32_t flags, void* stream) {
     if (!g || !x) return ET_E_INVALID_ARG;
-    return G(g)->init_f64(initial, (double*)x, (hipStream_t)stream);
+    return G(g)->init_f64(initial, (double*)x, (hipStream_t)stream, (flags & ET_INIT_PLAIN) != 0);
 }
-int et_graph_step_fr_async(et_graph* g, const void* x, void* y, uint32_t iteration, void* stream) {
+int et_graph_step_fr_async(et_graph* g, const void* x, void* y, uint32_t iteration, uint32_t flags, void* stream) {
     if (!g || !x || !y) return ET_E_INVALID_ARG;
-    return G(g)->step_fr((const uint4*)x, (uint4*)y, iteration, (hipStream_t)stream);
+    return G(g)->step_fr((const uint4*)x, (uint4*)y, iteration, flags, (hipStream_t)stream);
 }
 int et_graph_step_f64_async(et_graph* g, const void* x, void* y, uint32_t iteration, double alpha,
-                            const void* pretrust_pos, void* stream) {
+                            const void* pretrust_pos, uint32_t flags, void* stream) {
     if (!g || !x || !y) return ET_E_INVALID_ARG;
-    return G(g)->step_f64((const double*)x, (double*)y, iteration, alpha, (const double*)pretrust_pos, (hipStream_t)stream);
+    return G(g)->step_f64((const double*)x, (double*)y, iteration, alpha, (const double*)pretrust_pos, flags, (hipStream_t)stream);
 }
 int et_graph_unpermute_fr_async(et_graph* g, const void* x, void* out_slots, void* stream) {
     if (!g || !x || !out_slots) return ET_E_INVALID_ARG;

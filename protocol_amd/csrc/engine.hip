@@ -10,6 +10,7 @@
 // order, so every run and every GPU count produces identical bits.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -40,13 +41,21 @@ const char* last_error() { return g_last_error.c_str(); }
 static const uint32_t STATS_RING = 64;
 
 // ---------------------------------------------------------------------------------------------
-// kernels: normalisation (native.rs:305-314, once per graph)
+// Two forms of the same iteration.
+//
+// "Raw" form, used whenever the opinions are integers (the production case: an attestation value
+// is a u8, eigentrust/src/attestation.rs:304): the normalised weight c_ji = v_ji * inv(sum_j)
+// (native.rs:305-314) is never stored.  The vector exchanged between iterations holds
+// xs_j = s_j * inv(sum_j), an edge record holds the raw opinion, and
+//     new_s_i = sum_j v_ji * xs_j
+// which equals sum_j c_ji * s_j exactly in the field (multiplication is associative and
+// distributive) and up to rounding in f64.  An edge then costs 5 (Fr) or 7 (f64) streamed bytes
+// instead of 36 or 14.  The plain scores of a share's own rows stay in a private vector (`own`);
+// the step flagged ET_STEP_FINAL writes plain scores to the exchanged vector as well.
+//
+// "Weighted" form, for opinions that are arbitrary field elements: weights are normalised once
+// per graph (k_normalise_*) and the exchanged vector holds the plain scores.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_normalise_f64_u32(const uint32_t* __restrict__ col, const uint32_t* __restrict__ val,
-                                    const double* __restrict__ scale, double* __restrict__ w, size_t slots, Geometry g) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < slots) w[i] = (double)val[i] * scale[g.pos_of_col(col[i])];
-}
 __global__ void k_normalise_f64_fr(const uint32_t* __restrict__ col, const uint4* __restrict__ val,
                                    const double* __restrict__ scale, double* __restrict__ w, size_t slots, Geometry g) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,18 +66,6 @@ __global__ void k_normalise_f64_fr(const uint32_t* __restrict__ col, const uint4
     for (int k = 7; k >= 0; --k) d = d * 4294967296.0 + (double)v.v[k];
     w[i] = d * scale[g.pos_of_col(col[i])];
 }
-__global__ void k_normalise_fr_u32(const uint32_t* __restrict__ col, const uint32_t* __restrict__ val,
-                                   const uint4* __restrict__ scale, uint4* __restrict__ wlo,
-                                   uint4* __restrict__ whi, size_t slots, Geometry g) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= slots) return;
-    U256 k = u256_load(scale + 2 * (size_t)g.pos_of_col(col[i]));
-    Acc a = acc_zero();
-    acc_mac_u32(a, k, val[i]);
-    U256 w = acc_redc288(a);  // v * inv(sum) * 2^576 * 2^-288 = weight * 2^288
-    wlo[i] = make_uint4(w.v[0], w.v[1], w.v[2], w.v[3]);
-    whi[i] = make_uint4(w.v[4], w.v[5], w.v[6], w.v[7]);
-}
 __global__ void k_normalise_fr_fr(const uint32_t* __restrict__ col, const uint4* __restrict__ val,
                                   const uint4* __restrict__ scale, uint4* __restrict__ wlo,
                                   uint4* __restrict__ whi, size_t slots, Geometry g) {
@@ -76,164 +73,58 @@ __global__ void k_normalise_fr_fr(const uint32_t* __restrict__ col, const uint4*
     if (i >= slots) return;
     U256 k = u256_load(scale + 2 * (size_t)g.pos_of_col(col[i]));
     U256 v = u256_load(val + 2 * i);
-    Acc a = acc_zero();
-    acc_mac(a, k, v);
-    U256 w = acc_redc288(a);
+    U256 w = fr_mul_redc288(k, v);  // v * inv(sum) * 2^576 * 2^-288 = weight * 2^288
     wlo[i] = make_uint4(w.v[0], w.v[1], w.v[2], w.v[3]);
     whi[i] = make_uint4(w.v[4], w.v[5], w.v[6], w.v[7]);
 }
 
 // ---------------------------------------------------------------------------------------------
 // kernels: initial vector (native.rs:184-185, :317).  Writes this segment only.
+// `scale` (raw form) or null: the exchanged entry is initial * scale[row]; `own` (raw form) or null
+// receives the plain score.
 // ---------------------------------------------------------------------------------------------
 ET_DEV bool row_is_member(const Geometry& g, uint32_t local) {
     uint64_t q = ((uint64_t)(local >> 6) * g.n_seg + g.seg) * 64 + (local & 63);
     return q < g.n_active || (q >= g.n_active_pad && q < (uint64_t)g.n_active_pad + g.n_dangling);
 }
-__global__ void k_init_f64(Geometry g, double initial, double d0, double* __restrict__ x) {
+__global__ void k_init_f64(Geometry g, double initial, double d0, double* __restrict__ x,
+                           double* __restrict__ own, const double* __restrict__ scale) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t stride = g.seg_stride();
     if (i >= stride) return;
+    const size_t p = (size_t)g.seg * stride + i;
     double v = 0.0;
-    if (i < g.rows_cap) v = row_is_member(g, i) ? initial : 0.0;
-    else if (i == g.rows_cap) v = d0;
-    x[(size_t)g.seg * stride + i] = v;
+    if (i < g.rows_cap) {
+        v = row_is_member(g, i) ? initial : 0.0;
+        if (own) own[i] = v;
+        if (scale) v *= scale[p];
+    } else if (i == g.rows_cap) v = d0;
+    x[p] = v;
 }
-__global__ void k_init_fr(Geometry g, U256 initial, U256 d0, uint4* __restrict__ x) {
+__global__ void k_init_fr(Geometry g, U256 initial, U256 d0, uint4* __restrict__ x,
+                          uint4* __restrict__ own, const uint4* __restrict__ scale) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t stride = g.seg_stride();
     if (i >= stride) return;
+    const size_t p = (size_t)g.seg * stride + i;
     U256 v = u256_zero();
-    if (i < g.rows_cap) { if (row_is_member(g, i)) v = initial; }
-    else if (i == g.rows_cap) v = d0;
-    u256_store(x + 2 * ((size_t)g.seg * stride + i), v);
+    if (i < g.rows_cap) {
+        if (row_is_member(g, i)) v = initial;
+        if (own) u256_store(own + 2 * (size_t)i, v);
+        if (scale) v = fr_mul_redc288(v, u256_load(scale + 2 * p));
+    } else if (i == g.rows_cap) v = d0;
+    u256_store(x + 2 * p, v);
 }
 
 // ---------------------------------------------------------------------------------------------
 // kernels: one iteration
 // ---------------------------------------------------------------------------------------------
-static const int WPB_F64 = 16;  // wavefronts per workgroup: one 1024-thread workgroup per CU
-static const int WPB_FR = 8;    // two 512-thread workgroups per CU (the Fr kernel needs > 128 VGPRs)
-
-struct StepArgsF64 {
-    const WorkDesc* work;
-    const SliceDesc* slices;
-    const uint32_t* col;
-    const double* w;
-    const double* x;
-    double* y;
-    const double* pretrust;  // position order, may be null
-    double* res_part;        // [n_work] of this iteration
-    double* sum_part;
-    Geometry geo;
-    uint32_t n_work;
-    double inv_nm1;
-    double alpha;
-};
+static const int WPB_FR = 8;    // wavefronts per workgroup of the Fr kernels
 
 ET_DEV double wave_sum_f64(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
-}
-
-// Workgroup = 16 wavefronts sharing one LDS tile with the first geo.hot_f64 entries of every segment
-// (the most-gathered sources).  Each wavefront owns one work item (a run of slices).
-template <bool HAS_ALPHA>
-__global__ __launch_bounds__(WPB_F64 * 64) void k_step_f64(StepArgsF64 a) {
-    extern __shared__ double tile_f64[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const uint32_t stride = a.geo.seg_stride();
-    const uint32_t hot = a.geo.hot_f64;
-    const size_t my_base = (size_t)a.geo.seg * stride;
-    const double* __restrict__ xr = a.x;
-
-    for (uint32_t sg = 0; sg < a.geo.n_seg; ++sg)
-        for (uint32_t t = threadIdx.x; t < hot; t += WPB_F64 * 64) tile_f64[sg * hot + t] = xr[(size_t)sg * stride + t];
-
-    // score mass of dangling peers: fixed-order sum of every segment's partial sums
-    double D = 0.0;
-    {
-        const uint32_t total = a.geo.n_seg * a.geo.nd_cap;
-        for (uint32_t t = lane; t < total; t += 64) {
-            uint32_t sg = t / a.geo.nd_cap, k = t - sg * a.geo.nd_cap;
-            D += xr[(size_t)sg * stride + a.geo.rows_cap + k];
-        }
-        D = wave_sum_f64(D);
-    }
-    const double dterm = D * a.inv_nm1;
-    __syncthreads();
-
-    const uint32_t gw = blockIdx.x * WPB_F64 + wave;
-    if (gw >= a.n_work) return;
-    const WorkDesc wd = a.work[gw];
-    const bool dang = (wd.flags & WORK_DANGLING) != 0;
-
-    double res = 0.0, tot = 0.0, dacc = 0.0;
-    for (uint32_t s = wd.slice_begin; s < wd.slice_end; ++s) {
-        const SliceDesc sd = a.slices[s];
-        const uint32_t* __restrict__ cp = a.col + (size_t)sd.off * 64 + lane;
-        const double* __restrict__ wp = a.w + (size_t)sd.off * 64 + lane;
-        const bool reduce = (sd.nrows & SLICE_REDUCE) != 0;
-        const uint32_t row = reduce ? sd.row0 : sd.row0 + lane;
-        const bool live = reduce ? lane == 0 : (uint32_t)lane < (sd.nrows & 0xFFu);
-        // the row's current score is needed only in the epilogue: issue its load first
-        double old = 0.0;
-        if (live) old = xr[my_base + row];
-        double acc = 0.0;
-        {
-            // Batches of U steps; the source indices of batch b+1 are requested before batch b's
-            // products are formed, so a wave keeps about 3*U loads in flight.  The last batch may
-            // be partial: its surplus steps re-read the slice's last step (an L1 hit) with the
-            // weight forced to zero, which keeps the loop free of per-step branches.
-            constexpr int U = 4;
-            const uint32_t len = sd.len;
-            if (len > 0) {
-                const uint32_t last = len - 1;
-                uint32_t c[U];
-#pragma unroll
-                for (int i = 0; i < U; ++i) c[i] = cp[(size_t)min((uint32_t)i, last) * 64];
-                for (uint32_t k = 0; k < len; k += U) {
-                    double w[U], xv[U];
-#pragma unroll
-                    for (int i = 0; i < U; ++i) w[i] = wp[(size_t)min(k + i, last) * 64];
-#pragma unroll
-                    for (int i = 0; i < U; ++i) {
-                        const uint32_t sg = c[i] >> COL_SEG_SHIFT, loc = c[i] & COL_LOCAL_MASK;
-                        if (loc < hot) xv[i] = tile_f64[sg * hot + loc];
-                        else xv[i] = xr[(size_t)sg * stride + loc];
-                    }
-                    if (k + U < len) {
-#pragma unroll
-                        for (int i = 0; i < U; ++i) c[i] = cp[(size_t)min(k + U + i, last) * 64];
-                    }
-#pragma unroll
-                    for (int i = 0; i < U; ++i) acc = fma(k + i < len ? w[i] : 0.0, xv[i], acc);
-                }
-            }
-        }
-        if (reduce) acc = wave_sum_f64(acc);
-        if (live) {
-            double v = dang ? acc + (D - old) * a.inv_nm1 : acc + dterm;
-            if (HAS_ALPHA) {
-                double p = a.pretrust[my_base + row];
-                v = (1.0 - a.alpha) * v + a.alpha * p;
-            }
-            a.y[my_base + row] = v;
-            res += fabs(v - old);
-            tot += v;
-            if (dang) dacc += v;
-        }
-    }
-    res = wave_sum_f64(res);
-    tot = wave_sum_f64(tot);
-    dacc = wave_sum_f64(dacc);
-    if (lane == 0) {
-        a.res_part[gw] = res;
-        a.sum_part[gw] = tot;
-        if (dang) a.y[my_base + a.geo.rows_cap + wd.dslot] = dacc;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -242,30 +133,35 @@ __global__ __launch_bounds__(WPB_F64 * 64) void k_step_f64(StepArgsF64 a) {
 // LDS, and walks its edges in ascending SOURCE order: the edge records stream in coalesced, each
 // edge costs one 8-byte gather and one LDS atomic add.  Because every workgroup sweeps the source
 // range at the same pace, the part of the trust vector being gathered at any moment is a narrow
-// window that stays resident in the 4 MiB per-XCD L2 although the whole vector does not fit, and
-// the many consecutive edges of a popular source read one address.  (Measured: the row-per-lane
-// kernel above re-fetches the vector ~7x per XCD and iteration; see DESIGN.md.)
+// window that is shared through the 4 MiB per-XCD L2 although the whole vector does not fit, and
+// the many consecutive edges of a popular source read one address.
 // The LDS adds of one row arrive in no fixed order, so the last bits of an f64 score can differ
 // from run to run; the Fr variant is exact.
+// VT = uint8_t / uint32_t: raw form (per edge: source, accumulator slot, opinion);
+// VT = double: weighted form.
 // ---------------------------------------------------------------------------------------------
 struct StepArgsF64B {
     const uint64_t* bk_ptr;
     const uint32_t* grp;      // [f64_blocks][f64_rb / 64] 64-row group behind each accumulator slot, ~0 = none
     const uint32_t* col;
-    const double* w;
+    const void* w;            // VT per edge
     const uint16_t* row;
     const double* x;
     double* y;
+    double* own;              // raw form: plain scores of this segment's rows, updated in place
+    const double* scale;      // raw form: 1 / row sum by position
     const double* pretrust;
     double* res_part;   // [f64_blocks]
     double* sum_part;
     Geometry geo;
     double inv_nm1;
     double alpha;
+    uint32_t final_step;
 };
 
-template <bool HAS_ALPHA>
+template <typename VT, bool HAS_ALPHA>
 __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
+    constexpr bool RAW = sizeof(VT) != sizeof(double);
     extern __shared__ double acc_l[];
     __shared__ double red[3][16];
     const int lane = threadIdx.x & 63;
@@ -275,7 +171,9 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     const uint32_t stride = a.geo.seg_stride();
     const size_t my_base = (size_t)a.geo.seg * stride;
     const double* __restrict__ xr = a.x;
+    const VT* __restrict__ wr = static_cast<const VT*>(a.w);
     for (uint32_t i = threadIdx.x; i < RB; i += 1024) acc_l[i] = 0.0;
+    // score mass of dangling peers: fixed-order sum of every segment's partial sums
     double D = 0.0;
     {
         const uint32_t total = a.geo.n_seg * a.geo.nd_cap;
@@ -296,7 +194,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
         double w[U], xv[U];
         uint32_t r[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { c[u] = a.col[e + u * 1024]; w[u] = a.w[e + u * 1024]; r[u] = a.row[e + u * 1024]; }
+        for (int u = 0; u < U; ++u) { c[u] = a.col[e + u * 1024]; w[u] = (double)wr[e + u * 1024]; r[u] = a.row[e + u * 1024]; }
 #pragma unroll
         for (int u = 0; u < U; ++u) xv[u] = xr[(size_t)(c[u] >> COL_SEG_SHIFT) * stride + (c[u] & COL_LOCAL_MASK)];
 #pragma unroll
@@ -305,7 +203,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     for (; e < e1; e += 1024) {
         uint32_t c = a.col[e];
         double xv = xr[(size_t)(c >> COL_SEG_SHIFT) * stride + (c & COL_LOCAL_MASK)];
-        atomicAdd(&acc_l[a.row[e]], a.w[e] * xv);
+        atomicAdd(&acc_l[a.row[e]], (double)wr[e] * xv);
     }
     __syncthreads();
 
@@ -318,10 +216,15 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
         const bool active = q < a.geo.n_active;
         const bool dang = q >= a.geo.n_active_pad && q < (uint64_t)a.geo.n_active_pad + a.geo.n_dangling;
         if (!active && !dang) continue;
-        const double old = xr[my_base + row];
+        const double old = RAW ? a.own[row] : xr[my_base + row];
         double v = dang ? acc_l[lr] + (D - old) * a.inv_nm1 : acc_l[lr] + dterm;
         if (HAS_ALPHA) v = (1.0 - a.alpha) * v + a.alpha * a.pretrust[my_base + row];
-        a.y[my_base + row] = v;
+        if (RAW) {
+            a.own[row] = v;
+            a.y[my_base + row] = a.final_step ? v : v * a.scale[my_base + row];
+        } else {
+            a.y[my_base + row] = v;
+        }
         res += fabs(v - old);
         tot += v;
         if (dang) dacc += v;
@@ -340,18 +243,25 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fr variant: one lane per row over the 64-row slices (row-per-wavefront for long rows).
+// ---------------------------------------------------------------------------------------------
 struct StepArgsFr {
     const WorkDesc* work;
     const SliceDesc* slices;
     const uint32_t* col;
-    const uint4* wlo;
+    const uint4* wlo;      // weighted form: weight * 2^288, two planes
     const uint4* whi;
+    const void* val;       // raw form: opinion per slot (VT)
     const uint4* x;
     uint4* y;
+    uint4* own;            // raw form: plain scores of this segment's rows, updated in place
+    const uint4* scale;    // raw form: inv(row sum) * 2^576 by position
     uint4* sum_part;       // [n_work][2]
     uint32_t* chg_part;    // [n_work]
     Geometry geo;
     uint32_t n_work;
+    uint32_t final_step;
     U256 inv_nm1_w;        // inv(n_valid-1) * 2^288 mod r
 };
 
@@ -366,59 +276,85 @@ ET_DEV U256 fr_wave_sum(U256 v) {
     return v;
 }
 
+// Score mass D of the dangling peers (fixed-order integer sum of every segment's partial sums) as
+// the two values the rows need: sh_d = D + r (9 limbs), sh_pd = inv_nm1_w * D (17 limbs,
+// unreduced).  Called by the first wavefront of a workgroup; followed by __syncthreads().
+ET_DEV void fr_dangling_mass(const uint4* __restrict__ x, const Geometry& geo, const U256& inv_nm1_w, int lane,
+                             uint32_t* sh_d, uint32_t* sh_pd) {
+    const uint32_t stride = geo.seg_stride();
+    Acc d = acc_zero();
+    const uint32_t total = geo.n_seg * geo.nd_cap;
+    for (uint32_t t = lane; t < total; t += 64) {
+        uint32_t sg = t / geo.nd_cap, k = t - sg * geo.nd_cap;
+        U256 p = u256_load(x + 2 * ((size_t)sg * stride + geo.rows_cap + k));
+        acc_add_u256(d, p);
+    }
+    acc_wave_sum(d);  // < 2^(254+log2(total)) : limbs 0..8
+    Acc pd = acc_zero();
+    U256 dlo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dlo.v[i] = d.v[i];
+    acc_mac(pd, inv_nm1_w, dlo);
+    // + inv_nm1_w * d.v[8] * 2^256
+    {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t t = (uint64_t)inv_nm1_w.v[j] * d.v[8] + pd.v[8 + j] + c;
+            pd.v[8 + j] = (uint32_t)t;
+            c = t >> 32;
+        }
+        pd.v[16] += (uint32_t)c;
+    }
+    if (lane == 0) {
+        // D + r: the partial sums are reduced mod r, so D may be smaller than one of its own
+        // summands as an integer; (D + r - old) is the non-negative representative a dangling
+        // row needs
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            uint64_t t = (uint64_t)d.v[i] + (i < 8 ? FR_P[i] : 0u) + c;
+            sh_d[i] = (uint32_t)t;
+            c = t >> 32;
+        }
+#pragma unroll
+        for (int i = 0; i < 17; ++i) sh_pd[i] = pd.v[i];
+    }
+}
+// acc += inv_nm1_w * (D + r - old): the share a dangling row receives from the other dangling peers
+ET_DEV void fr_add_dangling_term(Acc& acc, const uint32_t* sh_d, const U256& old, const U256& inv_nm1_w) {
+    // (D + r - old) as a 9-limb integer: old < r, so no borrow out
+    uint32_t diff[9];
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        uint64_t t = (uint64_t)sh_d[i] - (i < 8 ? old.v[i] : 0u) - br;
+        diff[i] = (uint32_t)t;
+        br = (t >> 32) & 1;
+    }
+    U256 dlo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dlo.v[i] = diff[i];
+    acc_mac(acc, inv_nm1_w, dlo);
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uint64_t t = (uint64_t)inv_nm1_w.v[j] * diff[8] + acc.v[8 + j] + c;
+        acc.v[8 + j] = (uint32_t)t;
+        c = t >> 32;
+    }
+    acc.v[16] += (uint32_t)c;
+}
+
+// weighted form
 __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr(StepArgsFr a) {
-    extern __shared__ uint4 tile_fr[];                 // 2 x uint4 per hot source
-    __shared__ uint32_t sh_d[9];                       // integer sum of the partial sums, plus r (< 2^288)
-    __shared__ uint32_t sh_pd[17];                     // inv_nm1_w * sum of the partial sums, unreduced
+    __shared__ uint32_t sh_d[9];
+    __shared__ uint32_t sh_pd[17];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t stride = a.geo.seg_stride();
-    const uint32_t hot = a.geo.hot_fr;
     const size_t my_base = (size_t)a.geo.seg * stride;
-
-    for (uint32_t sg = 0; sg < a.geo.n_seg; ++sg)
-        for (uint32_t t = threadIdx.x; t < 2 * hot; t += WPB_FR * 64) tile_fr[2 * sg * hot + t] = a.x[2 * (size_t)sg * stride + t];
-
-    if (wave == 0) {
-        Acc d = acc_zero();
-        const uint32_t total = a.geo.n_seg * a.geo.nd_cap;
-        for (uint32_t t = lane; t < total; t += 64) {
-            uint32_t sg = t / a.geo.nd_cap, k = t - sg * a.geo.nd_cap;
-            U256 p = u256_load(a.x + 2 * ((size_t)sg * stride + a.geo.rows_cap + k));
-            acc_add_u256(d, p);
-        }
-        acc_wave_sum(d);  // < 2^(254+log2(total)) : limbs 0..8
-        Acc pd = acc_zero();
-        U256 dlo;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dlo.v[i] = d.v[i];
-        acc_mac(pd, a.inv_nm1_w, dlo);
-        // + inv_nm1_w * d.v[8] * 2^256
-        {
-            uint64_t c = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                uint64_t t = (uint64_t)a.inv_nm1_w.v[j] * d.v[8] + pd.v[8 + j] + c;
-                pd.v[8 + j] = (uint32_t)t;
-                c = t >> 32;
-            }
-            pd.v[16] += (uint32_t)c;
-        }
-        if (lane == 0) {
-            // D + r: the partial sums are reduced mod r, so D may be smaller than one of its own
-            // summands as an integer; (D + r - old) is the non-negative representative a dangling
-            // row needs
-            uint64_t c = 0;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                uint64_t t = (uint64_t)d.v[i] + (i < 8 ? FR_P[i] : 0u) + c;
-                sh_d[i] = (uint32_t)t;
-                c = t >> 32;
-            }
-#pragma unroll
-            for (int i = 0; i < 17; ++i) sh_pd[i] = pd.v[i];
-        }
-    }
+    if (wave == 0) fr_dangling_mass(a.x, a.geo, a.inv_nm1_w, lane, sh_d, sh_pd);
     __syncthreads();
     const uint32_t gw = blockIdx.x * WPB_FR + wave;
     if (gw >= a.n_work) return;
@@ -440,10 +376,7 @@ __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr(StepArgsFr a) {
         for (uint32_t k = 0; k < sd.len; ++k) {
             const uint32_t c = cp[(size_t)k * 64];
             U256 w = u256_from_planes(lop[(size_t)k * 64], hip_[(size_t)k * 64]);
-            const uint32_t sg = c >> COL_SEG_SHIFT, loc = c & COL_LOCAL_MASK;
-            U256 xv;
-            if (loc < hot) xv = u256_load(tile_fr + 2 * (sg * hot + loc));
-            else xv = u256_load(a.x + 2 * ((size_t)sg * stride + loc));
+            U256 xv = u256_load(a.x + 2 * ((size_t)(c >> COL_SEG_SHIFT) * stride + (c & COL_LOCAL_MASK)));
             acc_mac(acc, w, xv);
         }
         const bool reduce = (sd.nrows & SLICE_REDUCE) != 0;
@@ -452,33 +385,91 @@ __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr(StepArgsFr a) {
         const bool live = reduce ? lane == 0 : (uint32_t)lane < (sd.nrows & 0xFFu);
         if (live) {
             U256 old = u256_load(a.x + 2 * (my_base + row));
-            if (dang) {
-                // (D + r - old) as a 9-limb integer: old < r, so no borrow out
-                uint32_t diff[9];
-                uint64_t br = 0;
-#pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    uint64_t t = (uint64_t)sh_d[i] - (i < 8 ? old.v[i] : 0u) - br;
-                    diff[i] = (uint32_t)t;
-                    br = (t >> 32) & 1;
-                }
-                U256 dlo;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) dlo.v[i] = diff[i];
-                acc_mac(acc, a.inv_nm1_w, dlo);
-                uint64_t c = 0;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    uint64_t t = (uint64_t)a.inv_nm1_w.v[j] * diff[8] + acc.v[8 + j] + c;
-                    acc.v[8 + j] = (uint32_t)t;
-                    c = t >> 32;
-                }
-                acc.v[16] += (uint32_t)c;
-            } else {
-                acc_add(acc, PD);
-            }
+            if (dang) fr_add_dangling_term(acc, sh_d, old, a.inv_nm1_w);
+            else acc_add(acc, PD);
             U256 v = acc_redc288(acc);
             u256_store(a.y + 2 * (my_base + row), v);
+            changed += u256_eq(v, old) ? 0u : 1u;
+            tot = fr_add(tot, v);
+            if (dang) dacc = fr_add(dacc, v);
+        }
+    }
+    tot = fr_wave_sum(tot);
+    if (dang) dacc = fr_wave_sum(dacc);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) changed += __shfl_xor(changed, off, 64);
+    if (lane == 0) {
+        u256_store(a.sum_part + 2 * (size_t)gw, tot);
+        a.chg_part[gw] = changed;
+        if (dang) u256_store(a.y + 2 * (my_base + a.geo.rows_cap + wd.dslot), dacc);
+    }
+}
+
+// raw form: per slot a source index and the opinion (VT = uint8_t or uint32_t); the gathered
+// vector holds xs_j = s_j * inv(sum_j) * 2^288, the 320-bit sum of opinion * xs_j is reduced once.
+template <typename VT>
+__global__ __launch_bounds__(WPB_FR * 64) void k_step_fr_raw(StepArgsFr a) {
+    __shared__ uint32_t sh_d[9];
+    __shared__ uint32_t sh_pd[17];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t stride = a.geo.seg_stride();
+    const size_t my_base = (size_t)a.geo.seg * stride;
+    if (wave == 0) fr_dangling_mass(a.x, a.geo, a.inv_nm1_w, lane, sh_d, sh_pd);
+    __syncthreads();
+    const uint32_t gw = blockIdx.x * WPB_FR + wave;
+    if (gw >= a.n_work) return;
+    const WorkDesc wd = a.work[gw];
+    const bool dang = (wd.flags & WORK_DANGLING) != 0;
+
+    U256 tot = u256_zero(), dacc = u256_zero();
+    uint32_t changed = 0;
+    for (uint32_t s = wd.slice_begin; s < wd.slice_end; ++s) {
+        const SliceDesc sd = a.slices[s];
+        const uint32_t* __restrict__ cp = a.col + (size_t)sd.off * 64 + lane;
+        const VT* __restrict__ vp = static_cast<const VT*>(a.val) + (size_t)sd.off * 64 + lane;
+        Acc10 acc = acc10_zero();
+        // Batches of U steps with all U gathers in flight together; the last batch may be partial:
+        // its surplus steps re-read the slice's last step with the opinion forced to zero.
+        constexpr int U = 4;
+        const uint32_t len = sd.len;
+        if (len > 0) {
+            const uint32_t last = len - 1;
+            for (uint32_t k = 0; k < len; k += U) {
+                uint32_t c[U], v[U];
+#pragma unroll
+                for (int i = 0; i < U; ++i) {
+                    const size_t o = (size_t)min(k + i, last) * 64;
+                    c[i] = cp[o];
+                    v[i] = k + i < len ? (uint32_t)vp[o] : 0u;
+                }
+                U256 xv[U];
+#pragma unroll
+                for (int i = 0; i < U; ++i) xv[i] = u256_load(a.x + 2 * ((size_t)(c[i] >> COL_SEG_SHIFT) * stride + (c[i] & COL_LOCAL_MASK)));
+#pragma unroll
+                for (int i = 0; i < U; ++i) acc10_mac_u32(acc, xv[i], v[i]);
+            }
+        }
+        Acc full = acc_from_acc10(acc);
+        const bool reduce = (sd.nrows & SLICE_REDUCE) != 0;
+        if (reduce) acc_wave_sum(full);
+        const uint32_t row = reduce ? sd.row0 : sd.row0 + lane;
+        const bool live = reduce ? lane == 0 : (uint32_t)lane < (sd.nrows & 0xFFu);
+        if (live) {
+            U256 old = u256_load(a.own + 2 * (size_t)row);
+            if (dang) {
+                fr_add_dangling_term(full, sh_d, old, a.inv_nm1_w);
+            } else {
+                Acc PD;
+#pragma unroll
+                for (int i = 0; i < 17; ++i) PD.v[i] = sh_pd[i];
+                acc_add(full, PD);
+            }
+            U256 v = acc_redc288(full);
+            u256_store(a.own + 2 * (size_t)row, v);
+            // a dangling peer has no out-edges: its exchanged entry is never gathered
+            U256 out = a.final_step ? v : (dang ? u256_zero() : fr_mul_redc288(v, u256_load(a.scale + 2 * (my_base + row))));
+            u256_store(a.y + 2 * (my_base + row), out);
             changed += u256_eq(v, old) ? 0u : 1u;
             tot = fr_add(tot, v);
             if (dang) dacc = fr_add(dacc, v);
@@ -571,8 +562,8 @@ static int dev_upload(T** p, const std::vector<T>& v, uint64_t& total) {
 
 DeviceGraph::~DeviceGraph() {
     if (device >= 0) (void)hipSetDevice(device);
-    void* ptrs[] = {d_bk_ptr, d_bk_grp, d_bk_col, d_bk_row, d_bk_w, d_work, d_slices, d_col, d_w64, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
-                    d_chg_part, d_stat_out, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust};
+    void* ptrs[] = {d_bk_ptr, d_bk_grp, d_bk_col, d_bk_row, d_bk_w, d_work, d_slices, d_col, d_val, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
+                    d_chg_part, d_stat_out, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust, d_scale64, d_scale_fr, own64, own_fr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* e : ev_begin) (void)hipEventDestroy((hipEvent_t)e);
     for (void* e : ev_end) (void)hipEventDestroy((hipEvent_t)e);
@@ -608,78 +599,89 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     const size_t slots = (size_t)h.n_steps * 64;
     const size_t vec_len = (size_t)h.geo.n_seg * h.geo.seg_stride();
     g->vec_len = vec_len;
-    // raw opinions and source factors are only needed until the weights are computed
+    // raw form: opinions stay as they are (one byte each when they fit), the source factors stay
+    // resident; weighted form: opinions and factors are only needed until the weights are computed
+    g->raw = h.values_are_u32;
     uint64_t tmp_bytes = 0;
-    uint32_t* d_val32 = nullptr; uint4* d_valfr = nullptr; uint4* d_scale_fr = nullptr; double* d_scale64 = nullptr;
-    auto free_tmp = [&]() { if (d_val32) (void)hipFree(d_val32); if (d_valfr) (void)hipFree(d_valfr); if (d_scale_fr) (void)hipFree(d_scale_fr); if (d_scale64) (void)hipFree(d_scale64); };
-    if (h.values_are_u32) rc = dev_upload(&d_val32, h.val_u32, tmp_bytes);
-    else {
-        rc = dev_alloc(&d_valfr, slots * 2, tmp_bytes);
-        if (!rc && slots) HIP_TRY(hipMemcpy(d_valfr, h.val_fr.data(), slots * 32, hipMemcpyHostToDevice));
+    uint4* d_valfr = nullptr;
+    auto free_tmp = [&]() { if (d_valfr) (void)hipFree(d_valfr); d_valfr = nullptr; };
+    if (g->raw) {
+        uint32_t vmax = 0;
+        for (uint32_t v : h.val_u32) vmax = std::max(vmax, v);
+        g->val_bytes = vmax <= 255 ? 1 : 4;
     }
-    if (rc) { free_tmp(); return rc; }
+    // narrows 32-bit opinions to bytes when they fit
+    auto upload_values = [&](void** dst, const std::vector<uint32_t>& v) -> int {
+        if (g->val_bytes == 4) { uint32_t* p = nullptr; int r = dev_upload(&p, v, tot); *dst = p; return r; }
+        std::vector<uint8_t> v8(v.size());
+        for (size_t i = 0; i < v.size(); ++i) v8[i] = (uint8_t)v[i];
+        uint8_t* p = nullptr;
+        int r = dev_upload(&p, v8, tot);
+        *dst = p;
+        return r;
+    };
+    if ((rc = dev_upload(&g->d_scale64, h.scale_f64, tot))) return rc;
+    if ((rc = dev_alloc(&g->d_scale_fr, vec_len * 2, tot))) return rc;
+    HIP_TRY(hipMemcpy(g->d_scale_fr, h.scale_fr.data(), vec_len * 32, hipMemcpyHostToDevice));
     const unsigned nb = (unsigned)((slots + 255) / 256);
     if (g->variants & ET_VARIANT_F64) {
-        g->f64_blocked = getenv("ET_F64_SELL") == nullptr;   // experiment switch: row-per-lane f64 kernel
-        g->n_f64_parts = g->f64_blocked ? h.geo.f64_blocks : g->n_work;
-        if ((rc = dev_upload(&d_scale64, h.scale_f64, tmp_bytes))) { free_tmp(); return rc; }
-        if (g->f64_blocked) {
-            const size_t ne = h.bk_col.size();
-            const unsigned nbe = (unsigned)((ne + 255) / 256);
-            if ((rc = dev_upload(&g->d_bk_ptr, h.bk_ptr, tot)) || (rc = dev_upload(&g->d_bk_grp, h.bk_grp, tot)) || (rc = dev_upload(&g->d_bk_col, h.bk_col, tot)) ||
-                (rc = dev_upload(&g->d_bk_row, h.bk_row, tot)) || (rc = dev_alloc(&g->d_bk_w, ne, tot))) { free_tmp(); return rc; }
-            if (ne) {
-                if (h.values_are_u32) {
-                    uint32_t* d_bv = nullptr;
-                    if ((rc = dev_upload(&d_bv, h.bk_val_u32, tmp_bytes))) { free_tmp(); return rc; }
-                    hipLaunchKernelGGL(k_normalise_f64_u32, dim3(nbe), dim3(256), 0, 0, g->d_bk_col, d_bv, d_scale64, g->d_bk_w, ne, h.geo);
-                    HIP_TRY(hipDeviceSynchronize());
-                    (void)hipFree(d_bv);
-                } else {
-                    uint4* d_bv = nullptr;
-                    if ((rc = dev_alloc(&d_bv, ne * 2, tmp_bytes))) { free_tmp(); return rc; }
-                    HIP_TRY(hipMemcpy(d_bv, h.bk_val_fr.data(), ne * 32, hipMemcpyHostToDevice));
-                    hipLaunchKernelGGL(k_normalise_f64_fr, dim3(nbe), dim3(256), 0, 0, g->d_bk_col, d_bv, d_scale64, g->d_bk_w, ne, h.geo);
-                    HIP_TRY(hipDeviceSynchronize());
-                    (void)hipFree(d_bv);
-                }
-            }
+        g->n_f64_parts = h.geo.f64_blocks;
+        const size_t ne = h.bk_col.size();
+        if ((rc = dev_upload(&g->d_bk_ptr, h.bk_ptr, tot)) || (rc = dev_upload(&g->d_bk_grp, h.bk_grp, tot)) ||
+            (rc = dev_upload(&g->d_bk_col, h.bk_col, tot)) || (rc = dev_upload(&g->d_bk_row, h.bk_row, tot))) return rc;
+        if (g->raw) {
+            if ((rc = upload_values(&g->d_bk_w, h.bk_val_u32))) return rc;
+            if ((rc = dev_alloc(&g->own64, h.geo.rows_cap, tot))) return rc;
+            HIP_TRY(hipMemset(g->own64, 0, (size_t)h.geo.rows_cap * sizeof(double)));
         } else {
-            if ((rc = dev_alloc(&g->d_w64, slots, tot))) { free_tmp(); return rc; }
-            if (slots) {
-                if (h.values_are_u32) hipLaunchKernelGGL(k_normalise_f64_u32, dim3(nb), dim3(256), 0, 0, g->d_col, d_val32, d_scale64, g->d_w64, slots, h.geo);
-                else hipLaunchKernelGGL(k_normalise_f64_fr, dim3(nb), dim3(256), 0, 0, g->d_col, d_valfr, d_scale64, g->d_w64, slots, h.geo);
+            double* w = nullptr;
+            if ((rc = dev_alloc(&w, ne, tot))) return rc;
+            g->d_bk_w = w;
+            if (ne) {
+                uint4* d_bv = nullptr;
+                if ((rc = dev_alloc(&d_bv, ne * 2, tmp_bytes))) return rc;
+                HIP_TRY(hipMemcpy(d_bv, h.bk_val_fr.data(), ne * 32, hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(k_normalise_f64_fr, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, 0, g->d_bk_col, d_bv, g->d_scale64, w, ne, h.geo);
+                HIP_TRY(hipDeviceSynchronize());
+                (void)hipFree(d_bv);
             }
         }
         for (int i = 0; i < 2; ++i) {
-            if ((rc = dev_alloc(&g->vx[i], vec_len, tot))) { free_tmp(); return rc; }
+            if ((rc = dev_alloc(&g->vx[i], vec_len, tot))) return rc;
             HIP_TRY(hipMemset(g->vx[i], 0, vec_len * sizeof(double)));
         }
         if ((rc = dev_alloc(&g->out_f64, h.n, tot)) || (rc = dev_alloc(&g->d_res_part, (size_t)STATS_RING * g->n_f64_parts, tot)) ||
-            (rc = dev_alloc(&g->d_sum_part, (size_t)STATS_RING * g->n_f64_parts, tot))) { free_tmp(); return rc; }
+            (rc = dev_alloc(&g->d_sum_part, (size_t)STATS_RING * g->n_f64_parts, tot))) return rc;
     }
     if (g->variants & ET_VARIANT_FR) {
-        rc = dev_alloc(&d_scale_fr, vec_len * 2, tmp_bytes);
-        if (!rc) HIP_TRY(hipMemcpy(d_scale_fr, h.scale_fr.data(), vec_len * 32, hipMemcpyHostToDevice));
-        if (rc || (rc = dev_alloc(&g->d_wlo, slots, tot)) || (rc = dev_alloc(&g->d_whi, slots, tot))) { free_tmp(); return rc; }
-        if (slots) {
-            if (h.values_are_u32) hipLaunchKernelGGL(k_normalise_fr_u32, dim3(nb), dim3(256), 0, 0, g->d_col, d_val32, d_scale_fr, g->d_wlo, g->d_whi, slots, h.geo);
-            else hipLaunchKernelGGL(k_normalise_fr_fr, dim3(nb), dim3(256), 0, 0, g->d_col, d_valfr, d_scale_fr, g->d_wlo, g->d_whi, slots, h.geo);
+        if (g->raw) {
+            if ((rc = upload_values(&g->d_val, h.val_u32))) return rc;
+            if ((rc = dev_alloc(&g->own_fr, (size_t)h.geo.rows_cap * 2, tot))) return rc;
+            HIP_TRY(hipMemset(g->own_fr, 0, (size_t)h.geo.rows_cap * 32));
+        } else {
+            if ((rc = dev_alloc(&d_valfr, slots * 2, tmp_bytes))) return rc;
+            if (slots) HIP_TRY(hipMemcpy(d_valfr, h.val_fr.data(), slots * 32, hipMemcpyHostToDevice));
+            if ((rc = dev_alloc(&g->d_wlo, slots, tot)) || (rc = dev_alloc(&g->d_whi, slots, tot))) { free_tmp(); return rc; }
+            if (slots) hipLaunchKernelGGL(k_normalise_fr_fr, dim3(nb), dim3(256), 0, 0, g->d_col, d_valfr, g->d_scale_fr, g->d_wlo, g->d_whi, slots, h.geo);
+            HIP_TRY(hipDeviceSynchronize());
+            free_tmp();
         }
         for (int i = 0; i < 2; ++i) {
-            if ((rc = dev_alloc(&g->fx[i], vec_len * 2, tot))) { free_tmp(); return rc; }
+            if ((rc = dev_alloc(&g->fx[i], vec_len * 2, tot))) return rc;
             HIP_TRY(hipMemset(g->fx[i], 0, vec_len * 32));
         }
         if ((rc = dev_alloc(&g->out_fr, (size_t)h.n * 2, tot)) || (rc = dev_alloc(&g->d_frsum_part, (size_t)STATS_RING * g->n_work * 2, tot)) ||
-            (rc = dev_alloc(&g->d_chg_part, (size_t)STATS_RING * g->n_work, tot))) { free_tmp(); return rc; }
+            (rc = dev_alloc(&g->d_chg_part, (size_t)STATS_RING * g->n_work, tot))) return rc;
     }
-    if ((rc = dev_alloc(&g->d_stat_out, 64, tot))) { free_tmp(); return rc; }
-    // the LDS tiles exceed the 64 KiB a kernel may use without opting in
-    HIP_TRY(hipFuncSetAttribute((const void*)k_step_f64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_step_f64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_step_fr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_step_f64_blocked<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_step_f64_blocked<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    if ((rc = dev_alloc(&g->d_stat_out, 64, tot))) return rc;
+    // the LDS accumulators may exceed the 64 KiB a kernel may use without opting in
+    {
+        const int lds_max = 160 * 1024 - 1024;
+        const void* fns[] = {(const void*)k_step_f64_blocked<uint8_t, false>, (const void*)k_step_f64_blocked<uint8_t, true>,
+                             (const void*)k_step_f64_blocked<uint32_t, false>, (const void*)k_step_f64_blocked<uint32_t, true>,
+                             (const void*)k_step_f64_blocked<double, false>, (const void*)k_step_f64_blocked<double, true>};
+        for (const void* f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     free_tmp();
@@ -687,63 +689,61 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     return ET_OK;
 }
 
-int DeviceGraph::init_f64(double initial, double* x, hipStream_t st) {
+int DeviceGraph::init_f64(double initial, double* x, hipStream_t st, bool plain) {
     if (!(variants & ET_VARIANT_F64)) { set_error("graph was built without the f64 variant"); return ET_E_UNSUPPORTED; }
     uint32_t stride = geo.seg_stride();
     double d0 = (double)n_dangling_local * initial;
-    hipLaunchKernelGGL(k_init_f64, dim3((stride + 255) / 256), dim3(256), 0, st, geo, initial, d0, x);
+    hipLaunchKernelGGL(k_init_f64, dim3((stride + 255) / 256), dim3(256), 0, st, geo, initial, d0, x,
+                       raw && !plain ? own64 : nullptr, raw && !plain ? d_scale64 : nullptr);
     HIP_TRY(hipGetLastError());
     return ET_OK;
 }
-int DeviceGraph::init_fr(uint64_t lo, uint64_t hi, uint4* x, hipStream_t st) {
+int DeviceGraph::init_fr(uint64_t lo, uint64_t hi, uint4* x, hipStream_t st, bool plain) {
     if (!(variants & ET_VARIANT_FR)) { set_error("graph was built without the Fr variant"); return ET_E_UNSUPPORTED; }
     uint32_t stride = geo.seg_stride();
     Fr init = Fr::from_u128(lo, hi);
     Fr d0 = init * Fr::from_u64(n_dangling_local);
-    hipLaunchKernelGGL(k_init_fr, dim3((stride + 255) / 256), dim3(256), 0, st, geo, to_u256(init.to_raw()), to_u256(d0.to_raw()), x);
+    hipLaunchKernelGGL(k_init_fr, dim3((stride + 255) / 256), dim3(256), 0, st, geo, to_u256(init.to_raw()), to_u256(d0.to_raw()), x,
+                       raw && !plain ? own_fr : nullptr, raw && !plain ? d_scale_fr : nullptr);
     HIP_TRY(hipGetLastError());
     return ET_OK;
 }
-int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, hipStream_t st) {
+template <typename VT>
+static void launch_f64(const StepArgsF64B& a, unsigned blocks, size_t lds, hipStream_t st) {
+    if (a.alpha != 0.0) hipLaunchKernelGGL((k_step_f64_blocked<VT, true>), dim3(blocks), dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((k_step_f64_blocked<VT, false>), dim3(blocks), dim3(1024), lds, st, a);
+}
+int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, uint32_t flags, hipStream_t st) {
     if (!(variants & ET_VARIANT_F64)) { set_error("graph was built without the f64 variant"); return ET_E_UNSUPPORTED; }
     if (x == y) { set_error("step needs distinct input and output vectors"); return ET_E_INVALID_ARG; }
     if (alpha != 0.0 && !pretrust) { set_error("alpha != 0 needs a pre-trust vector"); return ET_E_INVALID_ARG; }
     const size_t ring = (size_t)(iteration % STATS_RING) * n_f64_parts;
-    if (f64_blocked) {
-        StepArgsF64B a;
-        a.bk_ptr = d_bk_ptr; a.grp = d_bk_grp; a.col = d_bk_col; a.w = d_bk_w; a.row = d_bk_row; a.x = x; a.y = y; a.pretrust = pretrust;
-        a.res_part = d_res_part + ring; a.sum_part = d_sum_part + ring;
-        a.geo = geo; a.inv_nm1 = inv_nm1; a.alpha = alpha;
-        const size_t lds = (size_t)geo.f64_rb * sizeof(double);
-        if (alpha != 0.0) hipLaunchKernelGGL(k_step_f64_blocked<true>, dim3(geo.f64_blocks), dim3(1024), lds, st, a);
-        else hipLaunchKernelGGL(k_step_f64_blocked<false>, dim3(geo.f64_blocks), dim3(1024), lds, st, a);
-        HIP_TRY(hipGetLastError());
-        return ET_OK;
-    }
-    StepArgsF64 a;
-    a.work = d_work; a.slices = d_slices; a.col = d_col; a.w = d_w64; a.x = x; a.y = y; a.pretrust = pretrust;
+    StepArgsF64B a;
+    a.bk_ptr = d_bk_ptr; a.grp = d_bk_grp; a.col = d_bk_col; a.w = d_bk_w; a.row = d_bk_row; a.x = x; a.y = y; a.pretrust = pretrust;
+    a.own = own64; a.scale = d_scale64;
     a.res_part = d_res_part + ring; a.sum_part = d_sum_part + ring;
-    a.geo = geo; a.n_work = n_work; a.inv_nm1 = inv_nm1; a.alpha = alpha;
-    if (n_work == 0) return ET_OK;
-    const unsigned grid = (n_work + WPB_F64 - 1) / WPB_F64;
-    const size_t lds = (size_t)geo.n_seg * geo.hot_f64 * sizeof(double);
-    if (alpha != 0.0) hipLaunchKernelGGL(k_step_f64<true>, dim3(grid), dim3(WPB_F64 * 64), lds, st, a);
-    else hipLaunchKernelGGL(k_step_f64<false>, dim3(grid), dim3(WPB_F64 * 64), lds, st, a);
+    a.geo = geo; a.inv_nm1 = inv_nm1; a.alpha = alpha; a.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u;
+    const size_t lds = (size_t)geo.f64_rb * sizeof(double);
+    if (!raw) launch_f64<double>(a, geo.f64_blocks, lds, st);
+    else if (val_bytes == 1) launch_f64<uint8_t>(a, geo.f64_blocks, lds, st);
+    else launch_f64<uint32_t>(a, geo.f64_blocks, lds, st);
     HIP_TRY(hipGetLastError());
     return ET_OK;
 }
-int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, hipStream_t st) {
+int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t flags, hipStream_t st) {
     if (!(variants & ET_VARIANT_FR)) { set_error("graph was built without the Fr variant"); return ET_E_UNSUPPORTED; }
     if (x == y) { set_error("step needs distinct input and output vectors"); return ET_E_INVALID_ARG; }
     StepArgsFr a;
-    a.work = d_work; a.slices = d_slices; a.col = d_col; a.wlo = d_wlo; a.whi = d_whi; a.x = x; a.y = y;
+    a.work = d_work; a.slices = d_slices; a.col = d_col; a.wlo = d_wlo; a.whi = d_whi; a.val = d_val; a.x = x; a.y = y;
+    a.own = own_fr; a.scale = d_scale_fr;
     size_t ring = (size_t)(iteration % STATS_RING) * n_work;
     a.sum_part = d_frsum_part + 2 * ring; a.chg_part = d_chg_part + ring;
-    a.geo = geo; a.n_work = n_work; a.inv_nm1_w = to_u256(inv_nm1_w);
+    a.geo = geo; a.n_work = n_work; a.inv_nm1_w = to_u256(inv_nm1_w); a.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u;
     if (n_work == 0) return ET_OK;
     const unsigned grid = (n_work + WPB_FR - 1) / WPB_FR;
-    const size_t lds = (size_t)geo.n_seg * geo.hot_fr * 32;
-    hipLaunchKernelGGL(k_step_fr, dim3(grid), dim3(WPB_FR * 64), lds, st, a);
+    if (!raw) hipLaunchKernelGGL(k_step_fr, dim3(grid), dim3(WPB_FR * 64), 0, st, a);
+    else if (val_bytes == 1) hipLaunchKernelGGL(k_step_fr_raw<uint8_t>, dim3(grid), dim3(WPB_FR * 64), 0, st, a);
+    else hipLaunchKernelGGL(k_step_fr_raw<uint32_t>, dim3(grid), dim3(WPB_FR * 64), 0, st, a);
     HIP_TRY(hipGetLastError());
     return ET_OK;
 }
@@ -820,22 +820,22 @@ int DeviceGraph::event_times(float* total_ms, uint32_t* pairs) {
 
 int DeviceGraph::run_f64(uint32_t iters, double initial, double alpha, hipStream_t st, bool record) {
     if (geo.n_seg != 1) { set_error("run needs the whole graph on one GPU"); return ET_E_UNSUPPORTED; }
-    int rc = init_f64(initial, vx[0], st);
+    int rc = init_f64(initial, vx[0], st, iters == 0);
     if (rc) return rc;
     const double* pre = nullptr;
     if (alpha != 0.0) {
-        // default pre-trust: the initial vector
+        // default pre-trust: the initial vector (plain scores, position order)
         if (!d_pretrust) {
             uint64_t dummy = 0;
             if ((rc = dev_alloc(&d_pretrust, vec_len, dummy))) return rc;
             device_bytes += dummy;
         }
-        HIP_TRY(hipMemcpyAsync(d_pretrust, vx[0], vec_len * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if ((rc = init_f64(initial, d_pretrust, st, true))) return rc;
         pre = d_pretrust;
     }
     if (record && (rc = record_begin(st))) return rc;
     for (uint32_t it = 0; it < iters; ++it)
-        if ((rc = step_f64(vx[it & 1], vx[(it + 1) & 1], it, alpha, pre, st))) return rc;
+        if ((rc = step_f64(vx[it & 1], vx[(it + 1) & 1], it, alpha, pre, it + 1 == iters ? ET_STEP_FINAL : 0u, st))) return rc;
     if (record && (rc = record_end(st))) return rc;
     if ((rc = unpermute_f64(vx[iters & 1], out_f64, st))) return rc;
     last_iters = iters;
@@ -843,11 +843,11 @@ int DeviceGraph::run_f64(uint32_t iters, double initial, double alpha, hipStream
 }
 int DeviceGraph::run_fr(uint32_t iters, uint64_t lo, uint64_t hi, hipStream_t st, bool record) {
     if (geo.n_seg != 1) { set_error("run needs the whole graph on one GPU"); return ET_E_UNSUPPORTED; }
-    int rc = init_fr(lo, hi, fx[0], st);
+    int rc = init_fr(lo, hi, fx[0], st, iters == 0);
     if (rc) return rc;
     if (record && (rc = record_begin(st))) return rc;
     for (uint32_t it = 0; it < iters; ++it)
-        if ((rc = step_fr(fx[it & 1], fx[(it + 1) & 1], it, st))) return rc;
+        if ((rc = step_fr(fx[it & 1], fx[(it + 1) & 1], it, it + 1 == iters ? ET_STEP_FINAL : 0u, st))) return rc;
     if (record && (rc = record_end(st))) return rc;
     if ((rc = unpermute_fr(fx[iters & 1], out_fr, st))) return rc;
     last_iters = iters;

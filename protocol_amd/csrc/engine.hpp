@@ -32,14 +32,22 @@ struct DeviceGraph {
     WorkDesc* d_work = nullptr;
     SliceDesc* d_slices = nullptr;
     uint32_t* d_col = nullptr;
-    double* d_w64 = nullptr;
-    bool f64_blocked = true;
+    // raw form (integer opinions): edge records keep the opinion (val_bytes = 1 or 4 each), the
+    // source factors stay resident and the plain scores of this share's rows live in own64/own_fr;
+    // weighted form (field-valued opinions): normalised weights in d_bk_w (double) / d_wlo, d_whi
+    bool raw = true;
+    int val_bytes = 4;
+    void* d_val = nullptr;
+    double* d_scale64 = nullptr;
+    uint4* d_scale_fr = nullptr;
+    double* own64 = nullptr;
+    uint4* own_fr = nullptr;
     uint32_t n_f64_parts = 0;
     uint64_t* d_bk_ptr = nullptr;
     uint32_t* d_bk_grp = nullptr;
     uint32_t* d_bk_col = nullptr;
     uint16_t* d_bk_row = nullptr;
-    double* d_bk_w = nullptr;
+    void* d_bk_w = nullptr;
     uint4* d_wlo = nullptr;
     uint4* d_whi = nullptr;
     uint32_t* d_pos = nullptr;
@@ -61,10 +69,11 @@ struct DeviceGraph {
     ~DeviceGraph();
     static int create(const HostGraph& h, int variants, int device, DeviceGraph** out);
 
-    int init_f64(double initial, double* x, hipStream_t st);
-    int init_fr(uint64_t lo, uint64_t hi, uint4* x, hipStream_t st);
-    int step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, hipStream_t st);
-    int step_fr(const uint4* x, uint4* y, uint32_t iteration, hipStream_t st);
+    // plain = true writes plain scores whatever the form (a vector that is read back, not iterated)
+    int init_f64(double initial, double* x, hipStream_t st, bool plain = false);
+    int init_fr(uint64_t lo, uint64_t hi, uint4* x, hipStream_t st, bool plain = false);
+    int step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, uint32_t flags, hipStream_t st);
+    int step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t flags, hipStream_t st);
     int unpermute_f64(const double* x, double* out, hipStream_t st);
     int unpermute_fr(const uint4* x, uint4* out, hipStream_t st);
     int stats_f64(uint32_t iteration, hipStream_t st, et_iter_stats* out);

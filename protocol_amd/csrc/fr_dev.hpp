@@ -221,6 +221,41 @@ ET_DEV U256 acc_redc288(Acc a) {
     return u256_sub_p_if_geq(r);
 }
 
+// 320-bit accumulator for sums of (32-bit opinion) x (field element): holds 2^34 such products
+struct Acc10 {
+    uint32_t v[10];
+};
+ET_DEV Acc10 acc10_zero() {
+    Acc10 a;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) a.v[i] = 0;
+    return a;
+}
+ET_DEV void acc10_mac_u32(Acc10& acc, const U256& a, uint32_t v) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uint64_t t = (uint64_t)a.v[j] * v + acc.v[j] + c;
+        acc.v[j] = (uint32_t)t;
+        c = t >> 32;
+    }
+    uint64_t t = (uint64_t)acc.v[8] + c;
+    acc.v[8] = (uint32_t)t;
+    acc.v[9] += (uint32_t)(t >> 32);
+}
+ET_DEV Acc acc_from_acc10(const Acc10& s) {
+    Acc a = acc_zero();
+#pragma unroll
+    for (int i = 0; i < 10; ++i) a.v[i] = s.v[i];
+    return a;
+}
+// a * b * 2^-288 mod r: the Montgomery product the kernels use for "times a stored factor"
+ET_DEV U256 fr_mul_redc288(const U256& a, const U256& b) {
+    Acc t = acc_zero();
+    acc_mac(t, a, b);
+    return acc_redc288(t);
+}
+
 // Wavefront-wide integer sum of accumulators; every lane receives the total.
 ET_DEV void acc_wave_sum(Acc& a) {
 #pragma unroll

@@ -131,17 +131,19 @@ class Graph:
         return st.residual_l1, st.sum_f64
 
     # stepping on caller-owned device vectors (raw device pointers as ints) ---------------------
-    def init_fr(self, x_ptr, initial=1000, stream=None):
-        check(lib().et_graph_init_fr_async(self._h, initial & (2**64 - 1), initial >> 64, x_ptr, stream))
+    def init_fr(self, x_ptr, initial=1000, stream=None, plain=False):
+        """Initial vector of this share; `plain=True` for a vector that is read back instead of iterated."""
+        check(lib().et_graph_init_fr_async(self._h, initial & (2**64 - 1), initial >> 64, x_ptr, 1 if plain else 0, stream))
 
-    def init_f64(self, x_ptr, initial=1000.0, stream=None):
-        check(lib().et_graph_init_f64_async(self._h, initial, x_ptr, stream))
+    def init_f64(self, x_ptr, initial=1000.0, stream=None, plain=False):
+        check(lib().et_graph_init_f64_async(self._h, initial, x_ptr, 1 if plain else 0, stream))
 
-    def step_fr(self, x_ptr, y_ptr, iteration, stream=None):
-        check(lib().et_graph_step_fr_async(self._h, x_ptr, y_ptr, iteration, stream))
+    def step_fr(self, x_ptr, y_ptr, iteration, stream=None, final=False):
+        """One iteration; `final=True` on the last step of a converge (its output holds plain scores)."""
+        check(lib().et_graph_step_fr_async(self._h, x_ptr, y_ptr, iteration, 1 if final else 0, stream))
 
-    def step_f64(self, x_ptr, y_ptr, iteration, alpha=0.0, pretrust_ptr=None, stream=None):
-        check(lib().et_graph_step_f64_async(self._h, x_ptr, y_ptr, iteration, alpha, pretrust_ptr, stream))
+    def step_f64(self, x_ptr, y_ptr, iteration, alpha=0.0, pretrust_ptr=None, stream=None, final=False):
+        check(lib().et_graph_step_f64_async(self._h, x_ptr, y_ptr, iteration, alpha, pretrust_ptr, 1 if final else 0, stream))
 
     def unpermute_fr(self, x_ptr, out_ptr, stream=None):
         check(lib().et_graph_unpermute_fr_async(self._h, x_ptr, out_ptr, stream))

@@ -77,20 +77,20 @@ class ShardedGraph:
             g.run_f64(num_iterations, initial, alpha, st, record)
             return
         x, y, out = self._buffers("f64")
-        g.init_f64(x.data_ptr(), initial, st)
-        self._all_gather(x)
         pre = None
-        if alpha != 0.0:
+        if alpha != 0.0:  # default pre-trust: the initial scores (only this share's segment is read)
             if "pre" not in self._vec:
-                self._vec["pre"] = torch.empty_like(x)
-            self._vec["pre"].copy_(x)
+                self._vec["pre"] = torch.zeros_like(x)
+            g.init_f64(self._vec["pre"].data_ptr(), initial, st, plain=True)
             pre = self._vec["pre"].data_ptr()
+        g.init_f64(x.data_ptr(), initial, st, plain=num_iterations == 0)
+        self._all_gather(x)
         bufs = (x, y)
         for it in range(num_iterations):
             a, b = bufs[it & 1], bufs[(it + 1) & 1]
             if record:
                 g.record_begin(st)
-            g.step_f64(a.data_ptr(), b.data_ptr(), it, alpha, pre, st)
+            g.step_f64(a.data_ptr(), b.data_ptr(), it, alpha, pre, st, final=it + 1 == num_iterations)
             if record:
                 g.record_end(st)
             self._all_gather(b)
@@ -103,14 +103,14 @@ class ShardedGraph:
             g.run_fr(num_iterations, initial, st, record)
             return
         x, y, out = self._buffers("fr")
-        g.init_fr(x.data_ptr(), initial, st)
+        g.init_fr(x.data_ptr(), initial, st, plain=num_iterations == 0)
         self._all_gather(x)
         bufs = (x, y)
         for it in range(num_iterations):
             a, b = bufs[it & 1], bufs[(it + 1) & 1]
             if record:
                 g.record_begin(st)
-            g.step_fr(a.data_ptr(), b.data_ptr(), it, st)
+            g.step_fr(a.data_ptr(), b.data_ptr(), it, st, final=it + 1 == num_iterations)
             if record:
                 g.record_end(st)
             self._all_gather(b)
