@@ -35,11 +35,16 @@ WORKLOADS = {
 
 
 def algorithmic_bytes(variant, nnz, rows):
-    """Bytes one iteration launch must move when every array is touched once (CSR of C^T with
-    pre-normalised weights): f64 nnz*(8+4) + rows*(4+8+8); Fr nnz*(32+4) + rows*(4+32+32)."""
+    """Bytes one iteration launch must move when every array is touched once.
+    f64: CSR of C^T with pre-normalised weights, nnz*(8+4) + rows*(4+8+8) -- the per-edge figure the
+    metric's roofline is quoted on; the kernel's own edge records are smaller (7 B: source, slot,
+    opinion byte).
+    Fr: the kernel iterates the factored form (raw opinion + source per edge, s*inv(sum) per row),
+    whose compulsory traffic is nnz*(4+4) + rows*(4+32*3); the weighted CSR form would be
+    nnz*36 + rows*68 and is reported beside it."""
     if variant == "f64":
         return nnz * 12 + rows * 20
-    return nnz * 36 + rows * 68
+    return nnz * 8 + rows * 100
 
 
 def main():
@@ -139,9 +144,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic.get("k_step_f64" if variant == "f64" else "k_step_fr"),
-                         "kernel": "k_step_f64_blocked" if variant == "f64" else "k_step_fr",
+                         "kernel": "k_step_f64_blocked<u8>" if variant == "f64" else "k_step_fr_raw<u8>",
                          "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": alg},
         }
+        if variant == "fr":
+            results[variant]["roofline"]["form"] = "factored (raw opinions, pre-scaled vector)"
+            results[variant]["roofline"]["weighted_csr_bytes_per_launch"] = int(info.nnz_local) * 36 + rows_local * 68
 
     # parity of the timed configuration: conservation of the score sum (native.rs:331-334)
     checks = {}
