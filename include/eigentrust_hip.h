@@ -44,7 +44,14 @@ enum {
     ET_E_NO_DEVICE = -9,
     ET_E_BUFFER_TOO_SMALL = -10,
     ET_E_OUT_OF_RANGE = -11,      /* slot / peer index >= number of slots                   */
-    ET_E_UNSUPPORTED = -12
+    ET_E_UNSUPPORTED = -12,
+    ET_E_THRESHOLD_RANGE = -13,   /* threshold/native.rs:37, :63  limb or threshold bound     */
+    ET_E_RATIO_DIGITS = -14,      /* utils.rs:340  more decimal digits than the limbs hold    */
+    ET_E_RATIO_MISMATCH = -15,    /* threshold/native.rs:81  num * den^-1 != score            */
+    ET_E_ZERO_LIMB = -16,         /* threshold/native.rs:79, :90  zero denominator (limb)     */
+    ET_E_BAD_DOMAIN = -17,        /* opinion/native.rs:76  attestation of another domain      */
+    ET_E_RATIONAL_TOO_LARGE = -18,/* eigentrust/src/lib.rs:222-229  magnitude over 32 bytes   */
+    ET_E_PARSE = -19              /* storage.rs:286-331, circuit.rs:128-132  malformed input  */
 };
 
 const char *et_strerror(int code);
@@ -276,6 +283,80 @@ int et_batch_converge_fr(uint32_t n_sets, uint32_t n, const uint8_t *member, con
 int et_synth_graph(uint32_t kind, uint32_t n, uint64_t target_edges, uint64_t seed,
                    uint32_t value_max, uint64_t *n_edges, uint32_t *from, uint32_t *to,
                    uint32_t *value);
+
+/* ------------------------------------------------------------------------------------------
+ * Around the converge path (host side): threshold check, score packaging, the client's CSV
+ * formats, the ET public-input layout.  No GPU work except inside et_local_scores.
+ * Rational numbers are little-endian magnitudes, as et_set_converge_rational writes them. */
+
+/* big_to_fe_rat (eigentrust-zk/src/utils.rs:332-354): both magnitudes scaled by the same power
+ * of ten so that the larger has num_limbs*power_of_ten digits, then cut into num_limbs limbs of
+ * power_of_ten decimal digits, least significant first (reference: 2 limbs of 72 digits,
+ * circuits/mod.rs:53-55).  ET_E_RATIO_DIGITS where the reference's usize subtraction panics. */
+int et_ratio_decompose(const uint8_t *num_le, size_t num_len, const uint8_t *den_le, size_t den_len,
+                       uint32_t num_limbs, uint32_t power_of_ten, et_fr *num_limbs_out,
+                       et_fr *den_limbs_out);
+/* Threshold::new + check_threshold (threshold/native.rs:33-96): *passed = 1 when the top limb of
+ * the numerator >= top limb of the denominator * threshold.  Every assert of the reference is an
+ * error code: ET_E_THRESHOLD_RANGE, ET_E_RATIO_DIGITS, ET_E_RATIO_MISMATCH, ET_E_ZERO_LIMB. */
+int et_threshold_check(const et_fr *score_fr, const uint8_t *num_le, size_t num_len,
+                       const uint8_t *den_le, size_t den_len, const et_fr *threshold,
+                       uint32_t num_limbs, uint32_t power_of_ten, uint32_t num_neighbours,
+                       uint64_t initial_lo, uint64_t initial_hi, int *passed);
+
+/* scalar_from_address (eigentrust/src/eth.rs:77-95): a 20-byte Ethereum address as a scalar. */
+int et_scalar_from_address(const uint8_t address[20], et_fr *out);
+
+/* Score (eigentrust/src/lib.rs:207-233): all magnitudes big-endian, right-aligned in 32 bytes. */
+typedef struct {
+    uint8_t address[20];
+    uint8_t score_fr[32];
+    uint8_t numerator[32];
+    uint8_t denominator[32];
+    uint8_t score[32];          /* floor(numerator / denominator) */
+} et_score;
+/* ET_E_RATIONAL_TOO_LARGE where the reference's `32 - len` index panics (lib.rs:222-229). */
+int et_score_pack(const uint8_t address[20], const et_fr *score_fr, const uint8_t *num_le,
+                  size_t num_len, const uint8_t *den_le, size_t den_len, et_score *out);
+
+/* SignedAttestationRaw (eigentrust/src/attestation.rs:283-330), the record of attestations.csv. */
+typedef struct {
+    uint8_t about[20];
+    uint8_t domain[20];
+    uint8_t value;
+    uint8_t message[32];
+    uint8_t sig_r[32];
+    uint8_t sig_s[32];
+    uint8_t rec_id;
+} et_attestation;
+/* attestations.csv (storage.rs:247-307; header about,domain,value,message,sig_r,sig_s,rec_id).
+ * parse: out may be NULL to count records; format/scores: *needed = bytes incl. the final NUL. */
+int et_attestations_csv_parse(const char *text, size_t len, et_attestation *out, size_t cap,
+                              size_t *count);
+int et_attestations_csv_format(const et_attestation *recs, size_t n, char *buf, size_t cap,
+                               size_t *needed);
+/* scores.csv (storage.rs:184-217; header peer_address,score_fr,numerator,denominator,score). */
+int et_scores_csv_format(const et_score *scores, size_t n, char *buf, size_t cap, size_t *needed);
+
+/* ETPublicInputs::to_bytes / from_bytes (eigentrust/src/circuit.rs:84-151):
+ * participants || scores || domain || opinions_hash as 32-byte little-endian scalars. */
+int et_public_inputs_pack(const et_fr *participants, const et_fr *scores, uint32_t n,
+                          const et_fr *domain, const et_fr *opinions_hash, uint8_t *out, size_t cap);
+int et_public_inputs_unpack(const uint8_t *bytes, size_t len, uint32_t n, et_fr *participants,
+                            et_fr *scores, et_fr *domain, et_fr *opinions_hash);
+
+/* calculate_scores (eigentrust/src/lib.rs:201-236 over et_circuit_setup :339-440) for attestations
+ * whose attester is already known: attesters[k] (20 bytes each) is the address recovered from
+ * attestation k's signature -- ECDSA recovery and verification (opinion/native.rs:84-87) are NOT
+ * done here.  Participants = all attesters and all `about` addresses in ascending order; a later
+ * attestation of the same (attester, about) pair replaces an earlier one; converge runs on the GPU,
+ * converge_rational on the host.  out may be NULL to query *n_participants.
+ * Errors: ET_E_SET_FULL (lib.rs:366-369), ET_E_INSUFFICIENT_PEERS (:371-374), ET_E_BAD_DOMAIN,
+ * ET_E_RATIONAL_TOO_LARGE, and those of et_set_converge. */
+int et_local_scores(const et_attestation *atts, const uint8_t *attesters, size_t n_att,
+                    const uint8_t domain[20], uint32_t num_neighbours, uint32_t num_iterations,
+                    uint64_t initial_lo, uint64_t initial_hi, et_score *out, size_t cap,
+                    size_t *n_participants);
 
 /* Field arithmetic self-test hook: runs the device multiply-accumulate + reduction used by the
  * Fr kernel on `count` (a, b) pairs and returns a[i]*b[i] mod r (canonical in, canonical out). */

@@ -22,6 +22,13 @@ ET_E_NO_DEVICE = -9
 ET_E_BUFFER_TOO_SMALL = -10
 ET_E_OUT_OF_RANGE = -11
 ET_E_UNSUPPORTED = -12
+ET_E_THRESHOLD_RANGE = -13
+ET_E_RATIO_DIGITS = -14
+ET_E_RATIO_MISMATCH = -15
+ET_E_ZERO_LIMB = -16
+ET_E_BAD_DOMAIN = -17
+ET_E_RATIONAL_TOO_LARGE = -18
+ET_E_PARSE = -19
 
 ET_VARIANT_FR = 1
 ET_VARIANT_F64 = 2
@@ -60,6 +67,17 @@ class EtPlanArrays(C.Structure):
                 ("scale_fr", C.POINTER(EtFr)), ("scale_f64", C.POINTER(C.c_double)),
                 ("inv_nm1_w", EtFr), ("n_active", C.c_uint32), ("n_active_pad", C.c_uint32),
                 ("n_dangling_pad", C.c_uint32), ("n_dangling_local", C.c_uint32)]
+
+
+class EtScore(C.Structure):
+    _fields_ = [("address", C.c_uint8 * 20), ("score_fr", C.c_uint8 * 32), ("numerator", C.c_uint8 * 32),
+                ("denominator", C.c_uint8 * 32), ("score", C.c_uint8 * 32)]
+
+
+class EtAttestation(C.Structure):
+    _fields_ = [("about", C.c_uint8 * 20), ("domain", C.c_uint8 * 20), ("value", C.c_uint8),
+                ("message", C.c_uint8 * 32), ("sig_r", C.c_uint8 * 32), ("sig_s", C.c_uint8 * 32),
+                ("rec_id", C.c_uint8)]
 
 
 class EtIterStats(C.Structure):
@@ -123,6 +141,16 @@ PROTOTYPES = {
     "et_batch_converge_fr": (i32, [u32, u32, vp, vp, u32, u64, u64, vp, vp]),
     "et_synth_graph": (i32, [u32, u32, u64, u64, u32, P(u64), vp, vp, vp]),
     "et_dev_fr_mul": (i32, [u32, vp, vp, vp]),
+    "et_ratio_decompose": (i32, [vp, C.c_size_t, vp, C.c_size_t, u32, u32, vp, vp]),
+    "et_threshold_check": (i32, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, u32, u32, u32, u64, u64, P(C.c_int)]),
+    "et_scalar_from_address": (i32, [vp, vp]),
+    "et_score_pack": (i32, [vp, vp, vp, C.c_size_t, vp, C.c_size_t, P(EtScore)]),
+    "et_attestations_csv_parse": (i32, [C.c_char_p, C.c_size_t, P(EtAttestation), C.c_size_t, P(C.c_size_t)]),
+    "et_attestations_csv_format": (i32, [P(EtAttestation), C.c_size_t, C.c_char_p, C.c_size_t, P(C.c_size_t)]),
+    "et_scores_csv_format": (i32, [P(EtScore), C.c_size_t, C.c_char_p, C.c_size_t, P(C.c_size_t)]),
+    "et_public_inputs_pack": (i32, [vp, vp, u32, vp, vp, vp, C.c_size_t]),
+    "et_public_inputs_unpack": (i32, [vp, C.c_size_t, u32, vp, vp, vp, vp]),
+    "et_local_scores": (i32, [P(EtAttestation), vp, C.c_size_t, vp, u32, u32, u64, u64, P(EtScore), C.c_size_t, P(C.c_size_t)]),
 }
 
 _lib = None

@@ -41,6 +41,13 @@ const char* et_strerror(int code) {
         case ET_E_BUFFER_TOO_SMALL: return "output buffer too small";
         case ET_E_OUT_OF_RANGE: return "index out of range";
         case ET_E_UNSUPPORTED: return "unsupported configuration";
+        case ET_E_THRESHOLD_RANGE: return "threshold or decimal limb bound out of range";
+        case ET_E_RATIO_DIGITS: return "rational score has more decimal digits than the limbs hold";
+        case ET_E_RATIO_MISMATCH: return "rational score does not match the field score";
+        case ET_E_ZERO_LIMB: return "denominator (or its top decimal limb) is zero";
+        case ET_E_BAD_DOMAIN: return "attestation belongs to another domain";
+        case ET_E_RATIONAL_TOO_LARGE: return "rational score does not fit 32 bytes";
+        case ET_E_PARSE: return "malformed input";
         default: return "unknown error";
     }
 }

@@ -1,0 +1,86 @@
+"""calculate_scores end to end (eigentrust/src/lib.rs:201-236 over :339-440): attestation records
+in, score records out, converge on the GPU.  The reference's committed CLI assets are the literal
+golden: attestations.csv -> scores.csv byte for byte (the attester of the single record is Anvil
+account 0, eigentrust/src/eth.rs:153-160; signature recovery is outside this library)."""
+import os
+import random
+from fractions import Fraction
+
+import pytest
+
+import eigentrust_ref as ref
+import protocol_amd as pa
+from protocol_amd import _ffi
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+ASSETS = os.path.join(GOLDEN, "cli_assets")
+ANVIL_0 = "0xf39fd6e51aad88f6f4ce6ab8827279cfffb92266"
+
+
+def test_cli_assets_scores_csv_byte_for_byte():
+    atts = pa.read_attestations_csv(open(os.path.join(ASSETS, "attestations.csv")).read())
+    scores = pa.calculate_scores(atts, [ANVIL_0])
+    assert pa.write_scores_csv(scores) == open(os.path.join(ASSETS, "scores.csv")).read()
+    for s in scores:   # the threshold check the reference runs on each score (lib.rs:480-505)
+        fr = int.from_bytes(s.score_fr, "big")
+        assert pa.Threshold(fr, s.rational, 999).check_threshold() is True
+        assert pa.Threshold(fr, s.rational, 1001).check_threshold() is False
+
+
+def att(about, value, domain=bytes(20)):
+    return pa.SignedAttestationRaw(about, domain, value, bytes(32), bytes(32), bytes(32), 0)
+
+
+def expected_scores(atts, attesters, nn, iters, init):
+    """The reference's set building order restated with the Python checker."""
+    parts = sorted({a.about for a in atts} | set(attesters))
+    s = ref.EigenTrustSet(nn, iters, init, 0)
+    for p in parts:
+        s.add_member(int.from_bytes(p, "big"))
+    matrix = {p: [0] * nn for p in parts}
+    for a, who in zip(atts, attesters):
+        matrix[who][parts.index(a.about)] = a.value
+    for p in parts:
+        if p in set(attesters):
+            s.update_op(int.from_bytes(p, "big"), matrix[p])
+    return parts, s.converge(), s.converge_rational()
+
+
+@pytest.mark.parametrize("nn,iters,seed", [(4, 20, 1), (4, 3, 2), (8, 4, 3), (16, 2, 4), (6, 20, 5)])
+def test_random_attestation_lists_match_the_restatement(nn, iters, seed):
+    rng = random.Random(seed)
+    peers = [bytes(rng.randrange(256) for _ in range(20)) for _ in range(nn)]
+    atts, who = [], []
+    for _ in range(rng.randrange(nn, 3 * nn)):
+        f, t = rng.sample(peers[: max(2, nn - 1)], 2)
+        atts.append(att(t, rng.randrange(0, 256)))
+        who.append(f)
+    atts.append(att(atts[0].about, 77))     # a later record of the same pair replaces the earlier one
+    who.append(who[0])
+    parts, want_fr, want_rat = expected_scores(atts, who, nn, iters, 1000)
+    fits = all(max(q.numerator, q.denominator).bit_length() <= 256 for q in want_rat[: len(parts)])
+    if not fits:                             # lib.rs:222-229 panics in the reference
+        with pytest.raises(pa.EigenTrustError) as e:
+            pa.calculate_scores(atts, who, num_neighbours=nn, num_iterations=iters)
+        assert e.value.code == _ffi.ET_E_RATIONAL_TOO_LARGE
+        return
+    got = pa.calculate_scores(atts, who, num_neighbours=nn, num_iterations=iters)
+    assert [g.address for g in got] == parts
+    for g, fr, q in zip(got, want_fr, want_rat):
+        assert int.from_bytes(g.score_fr, "big") == fr
+        assert g.rational == q
+        assert int.from_bytes(g.score_hex, "big") == q.numerator // q.denominator
+
+
+def test_calculate_scores_errors():
+    a, b, c, d, e = (bytes([i]) * 20 for i in range(1, 6))
+    with pytest.raises(pa.EigenTrustError) as err:           # lib.rs:366-369
+        pa.calculate_scores([att(b, 1), att(c, 1), att(d, 1), att(e, 1)], [a, a, a, a], num_neighbours=4)
+    assert err.value.code == _ffi.ET_E_SET_FULL
+    with pytest.raises(pa.EigenTrustError) as err:           # lib.rs:371-374
+        pa.calculate_scores([att(a, 1)], [a])
+    assert err.value.code == _ffi.ET_E_INSUFFICIENT_PEERS
+    with pytest.raises(pa.EigenTrustError) as err:           # opinion/native.rs:76
+        pa.calculate_scores([att(b, 1, domain=bytes([9]) * 20)], [a])
+    assert err.value.code == _ffi.ET_E_BAD_DOMAIN
