@@ -51,7 +51,9 @@ enum {
     ET_E_ZERO_LIMB = -16,         /* threshold/native.rs:79, :90  zero denominator (limb)     */
     ET_E_BAD_DOMAIN = -17,        /* opinion/native.rs:76  attestation of another domain      */
     ET_E_RATIONAL_TOO_LARGE = -18,/* eigentrust/src/lib.rs:222-229  magnitude over 32 bytes   */
-    ET_E_PARSE = -19              /* storage.rs:286-331, circuit.rs:128-132  malformed input  */
+    ET_E_PARSE = -19,             /* storage.rs:286-331, circuit.rs:128-132  malformed input  */
+    ET_E_BAD_SIGNATURE = -20,     /* ecdsa/native.rs:202-203, :316, :322-327  unwrap / assert */
+    ET_E_BAD_ABOUT = -21          /* opinion/native.rs:75  attestation about another peer     */
 };
 
 const char *et_strerror(int code);
@@ -357,6 +359,44 @@ int et_local_scores(const et_attestation *atts, const uint8_t *attesters, size_t
                     const uint8_t domain[20], uint32_t num_neighbours, uint32_t num_iterations,
                     uint64_t initial_lo, uint64_t initial_hi, et_score *out, size_t cap,
                     size_t *n_participants);
+
+/* ------------------------------------------------------------------------------------------
+ * Opinion validation crypto (host side): what turns signed attestation records into the score
+ * rows update_op stores.  Public keys are 64 bytes: x then y, each little-endian (the layout of
+ * PublicKey::to_bytes, ecdsa/native.rs:124-131). */
+
+/* Poseidon 5x5 permutation (poseidon/native/mod.rs:34-97; known answer :122-146) and the sponge
+ * over it (poseidon/native/sponge.rs:46-68). */
+int et_poseidon5_permute(const et_fr *in /* 5 */, et_fr *out /* 5 */);
+int et_poseidon5_sponge(const et_fr *in, size_t n, et_fr *out);
+int et_keccak256(const uint8_t *data, size_t len, uint8_t out[32]);
+/* Attestation::hash over (about, domain, value, message, 0) with the scalar conversions of
+ * AttestationEth::to_attestation_fr (dynamic_sets/native.rs:96-104, attestation.rs:81-115). */
+int et_attestation_hash(const et_attestation *att, et_fr *out);
+/* SignedAttestationEth::recover_public_key + address_from_ecdsa_key for n records
+ * (attestation.rs:215-239, ecdsa/native.rs:298-331, eth.rs:70-74): attesters = n*20 bytes,
+ * public_keys = n*64 bytes or NULL.  ET_E_BAD_SIGNATURE where the reference unwraps or asserts. */
+int et_attestations_recover(const et_attestation *atts, size_t n, uint8_t *attesters,
+                            uint8_t *public_keys);
+/* secret * G and its Ethereum address (ecdsa/native.rs:254-262, :90-111); for tests and tools. */
+int et_secp256k1_public_key(const uint8_t secret_le[32], uint8_t public_key[64], uint8_t address[20]);
+/* Opinion::validate (opinion/native.rs:63-109) for one attester: atts has num_neighbours records,
+ * present[i] == 0 (or a NULL `present` = all present) marks an entry the reference fills with
+ * empty_with_about (dynamic_sets/native.rs:209-219); set_addresses = num_neighbours * 20 bytes,
+ * zero = empty slot.  scores[i] = value when the signature verifies, the slot is occupied and
+ * the key is not the default key, else 0; op_hash = sponge of the per-entry hashes.
+ * ET_E_NOT_MEMBER (:67), ET_E_BAD_ABOUT (:75), ET_E_BAD_DOMAIN (:76). */
+int et_opinion_validate(const uint8_t public_key[64], const et_attestation *atts,
+                        const uint8_t *present, const uint8_t *set_addresses, uint32_t num_neighbours,
+                        const uint8_t domain[20], et_fr *scores, et_fr *op_hash);
+/* et_circuit_setup without the circuit (eigentrust/src/lib.rs:339-466): recovers the attesters,
+ * builds the participant set and the attestation matrix, validates every opinion, runs converge
+ * (GPU) and converge_rational (host), packs the scores and, when public_inputs is not NULL, the
+ * ETPublicInputs bytes ((2*num_neighbours + 2) * 32).  out may be NULL to query *n_participants. */
+int et_et_setup(const et_attestation *atts, size_t n_att, const uint8_t domain[20],
+                uint32_t num_neighbours, uint32_t num_iterations, uint64_t initial_lo,
+                uint64_t initial_hi, et_score *out, size_t cap, size_t *n_participants,
+                uint8_t *public_inputs, size_t public_inputs_cap);
 
 /* Field arithmetic self-test hook: runs the device multiply-accumulate + reduction used by the
  * Fr kernel on `count` (a, b) pairs and returns a[i]*b[i] mod r (canonical in, canonical out). */

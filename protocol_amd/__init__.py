@@ -7,5 +7,7 @@ from ._ffi import EigenTrustError, LIB_PATH, lib  # noqa: F401
 from .eigentrust_set import (EigenTrustSet, INITIAL_SCORE, MIN_PEER_COUNT, NUM_ITERATIONS,  # noqa: F401
                              NUM_NEIGHBOURS)
 from .graph import Batch, Graph, Plan, R_MODULUS, fr_bytes_from_ints, fr_ints_from_bytes, synth_graph  # noqa: F401
-from .scores import (ETPublicInputs, Score, SignedAttestationRaw, Threshold, big_to_fe_rat, calculate_scores,  # noqa: F401
-                     pack_score, read_attestations_csv, scalar_from_address, write_attestations_csv, write_scores_csv)
+from .scores import (ETPublicInputs, Score, SignedAttestationRaw, Threshold, attestation_hash, big_to_fe_rat,  # noqa: F401
+                     calculate_scores, et_circuit_setup, keccak256, opinion_validate, pack_score, poseidon5_permute,
+                     poseidon5_sponge, public_key_of_secret, read_attestations_csv, recover_attesters,
+                     scalar_from_address, write_attestations_csv, write_scores_csv)

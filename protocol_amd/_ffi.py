@@ -29,6 +29,8 @@ ET_E_ZERO_LIMB = -16
 ET_E_BAD_DOMAIN = -17
 ET_E_RATIONAL_TOO_LARGE = -18
 ET_E_PARSE = -19
+ET_E_BAD_SIGNATURE = -20
+ET_E_BAD_ABOUT = -21
 
 ET_VARIANT_FR = 1
 ET_VARIANT_F64 = 2
@@ -150,6 +152,14 @@ PROTOTYPES = {
     "et_scores_csv_format": (i32, [P(EtScore), C.c_size_t, C.c_char_p, C.c_size_t, P(C.c_size_t)]),
     "et_public_inputs_pack": (i32, [vp, vp, u32, vp, vp, vp, C.c_size_t]),
     "et_public_inputs_unpack": (i32, [vp, C.c_size_t, u32, vp, vp, vp, vp]),
+    "et_poseidon5_permute": (i32, [vp, vp]),
+    "et_poseidon5_sponge": (i32, [vp, C.c_size_t, vp]),
+    "et_keccak256": (i32, [vp, C.c_size_t, vp]),
+    "et_attestation_hash": (i32, [P(EtAttestation), vp]),
+    "et_attestations_recover": (i32, [P(EtAttestation), C.c_size_t, vp, vp]),
+    "et_secp256k1_public_key": (i32, [vp, vp, vp]),
+    "et_opinion_validate": (i32, [vp, P(EtAttestation), vp, vp, u32, vp, vp, vp]),
+    "et_et_setup": (i32, [P(EtAttestation), C.c_size_t, vp, u32, u32, u64, u64, P(EtScore), C.c_size_t, P(C.c_size_t), vp, C.c_size_t]),
     "et_local_scores": (i32, [P(EtAttestation), vp, C.c_size_t, vp, u32, u32, u64, u64, P(EtScore), C.c_size_t, P(C.c_size_t)]),
 }
 

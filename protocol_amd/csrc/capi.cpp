@@ -48,6 +48,8 @@ const char* et_strerror(int code) {
         case ET_E_BAD_DOMAIN: return "attestation belongs to another domain";
         case ET_E_RATIONAL_TOO_LARGE: return "rational score does not fit 32 bytes";
         case ET_E_PARSE: return "malformed input";
+        case ET_E_BAD_SIGNATURE: return "signature does not recover or verify";
+        case ET_E_BAD_ABOUT: return "attestation is about another peer than its slot";
         default: return "unknown error";
     }
 }

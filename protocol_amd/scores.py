@@ -168,10 +168,101 @@ def write_scores_csv(scores):
     return _format(lib().et_scores_csv_format, arr, len(scores))
 
 
-def calculate_scores(attestations, attesters, domain=bytes(20), num_neighbours=4, num_iterations=20, initial_score=1000):
-    """Client::calculate_scores (lib.rs:201-236) for attestations whose attester addresses are known
-    (`attesters[k]` = the address recovered from attestation k's signature; recovery is not done here).
+def poseidon5_permute(state):
+    """poseidon/native/mod.rs:34-97 on five field elements."""
+    inp = (_ffi.EtFr * 5)(*[_fr(v) for v in state])
+    out = (_ffi.EtFr * 5)()
+    check(lib().et_poseidon5_permute(inp, out))
+    return [int.from_bytes(bytes(e.b), "little") for e in out]
+
+
+def poseidon5_sponge(values):
+    """poseidon/native/sponge.rs:46-68."""
+    n = len(values)
+    inp = (_ffi.EtFr * max(1, n))(*[_fr(v) for v in values])
+    out = _ffi.EtFr()
+    check(lib().et_poseidon5_sponge(inp, n, C.byref(out)))
+    return int.from_bytes(bytes(out.b), "little")
+
+
+def keccak256(data):
+    out = (C.c_uint8 * 32)()
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\0")
+    check(lib().et_keccak256(buf, len(data), out))
+    return bytes(out)
+
+
+def attestation_hash(att):
+    out = _ffi.EtFr()
+    c = att._to_c()
+    check(lib().et_attestation_hash(C.byref(c), C.byref(out)))
+    return int.from_bytes(bytes(out.b), "little")
+
+
+def recover_attesters(attestations, with_keys=False):
+    """SignedAttestationEth::recover_public_key + address_from_ecdsa_key for every record."""
+    n = len(attestations)
+    arr = _c_attestations(attestations)
+    who = (C.c_uint8 * max(20, 20 * n))()
+    keys = (C.c_uint8 * max(64, 64 * n))()
+    check(lib().et_attestations_recover(arr, n, who, keys))
+    addrs = [bytes(who[20 * k:20 * k + 20]) for k in range(n)]
+    if not with_keys:
+        return addrs
+    return addrs, [bytes(keys[64 * k:64 * k + 64]) for k in range(n)]
+
+
+def public_key_of_secret(secret):
+    """(64-byte key: x, y little-endian; 20-byte address) of a secp256k1 secret."""
+    sk = (C.c_uint8 * 32).from_buffer_copy(int(secret).to_bytes(32, "little"))
+    pk, ad = (C.c_uint8 * 64)(), (C.c_uint8 * 20)()
+    check(lib().et_secp256k1_public_key(sk, pk, ad))
+    return bytes(pk), bytes(ad)
+
+
+def opinion_validate(public_key, attestations, set_addresses, domain=bytes(20)):
+    """Opinion::validate (opinion/native.rs:63-109): `attestations[i]` is a SignedAttestationRaw or
+    None (filled with empty_with_about as update_op does).  Returns (scores, op_hash)."""
+    nn = len(set_addresses)
+    arr = (_ffi.EtAttestation * nn)()
+    present = (C.c_uint8 * nn)()
+    for i, a in enumerate(attestations):
+        if a is not None:
+            arr[i] = a._to_c()
+            present[i] = 1
+    addrs = (C.c_uint8 * (20 * nn))()
+    for i, a in enumerate(set_addresses):
+        C.memmove(C.byref(addrs, 20 * i), bytes(_addr(a)), 20)
+    pk = (C.c_uint8 * 64).from_buffer_copy(bytes(public_key))
+    scores = (_ffi.EtFr * nn)()
+    op_hash = _ffi.EtFr()
+    check(lib().et_opinion_validate(pk, arr, present, addrs, nn, _addr(domain), scores, C.byref(op_hash)))
+    conv = lambda e: int.from_bytes(bytes(e.b), "little")
+    return [conv(e) for e in scores], conv(op_hash)
+
+
+def et_circuit_setup(attestations, domain=bytes(20), num_neighbours=4, num_iterations=20, initial_score=1000):
+    """Client::et_circuit_setup without the circuit (lib.rs:339-466): signatures are recovered and
+    verified, opinions validated, converge runs on the GPU.  Returns (scores, ETPublicInputs)."""
+    n = len(attestations)
+    arr = _c_attestations(attestations)
+    count = C.c_size_t(0)
+    dom = _addr(domain)
+    args = (arr, n, dom, num_neighbours, num_iterations, initial_score & (2**64 - 1), initial_score >> 64)
+    check(lib().et_et_setup(*args, None, 0, C.byref(count), None, 0))
+    out = (_ffi.EtScore * max(1, count.value))()
+    pub = (C.c_uint8 * ((2 * num_neighbours + 2) * 32))()
+    check(lib().et_et_setup(*args, out, count.value, C.byref(count), pub, len(pub)))
+    return [Score._from_c(c) for c in out[:count.value]], ETPublicInputs.from_bytes(bytes(pub), num_neighbours)
+
+
+def calculate_scores(attestations, attesters=None, domain=bytes(20), num_neighbours=4, num_iterations=20, initial_score=1000):
+    """Client::calculate_scores (lib.rs:201-236).  With `attesters=None` the attester of every record
+    is recovered from its signature and every opinion is verified, as in the reference; a list of
+    addresses (`attesters[k]` for attestation k) skips recovery and verification.
     Runs converge on the GPU and converge_rational on the host."""
+    if attesters is None:
+        return et_circuit_setup(attestations, domain, num_neighbours, num_iterations, initial_score)[0]
     n = len(attestations)
     arr = _c_attestations(attestations)
     who = (C.c_uint8 * max(20, 20 * n))()

@@ -84,3 +84,51 @@ def test_calculate_scores_errors():
     with pytest.raises(pa.EigenTrustError) as err:           # opinion/native.rs:76
         pa.calculate_scores([att(b, 1, domain=bytes([9]) * 20)], [a])
     assert err.value.code == _ffi.ET_E_BAD_DOMAIN
+
+
+# ---- signed path: recovery and verification included (lib.rs:339-466) -------------------------------
+import crypto_ref as cref  # noqa: E402
+
+
+def signed(secret, about, value, rng, domain=bytes(20)):
+    h = cref.attestation_hash(about, domain, value, bytes(32))
+    r, s, odd = cref.sign(secret, h, rng.randrange(1, cref.SECP_N))
+    return pa.SignedAttestationRaw(about, domain, value, bytes(32), r.to_bytes(32, "little"), s.to_bytes(32, "little"), odd)
+
+
+def test_cli_assets_from_signatures_alone():
+    atts = pa.read_attestations_csv(open(os.path.join(ASSETS, "attestations.csv")).read())
+    scores, pub = pa.et_circuit_setup(atts)
+    assert pa.write_scores_csv(scores) == open(os.path.join(ASSETS, "scores.csv")).read()
+    a = atts[0]
+    assert pub.participants == [int.from_bytes(a.about, "big"), int(ANVIL_0, 16), 0, 0]
+    assert pub.scores == [1000, 1000, 0, 0] and pub.domain == 0
+    h = cref.attestation_hash(a.about, a.domain, a.value, a.message)
+    assert pub.opinion_hash == cref.sponge([cref.sponge([h, 0, 0, 0])])     # opinion/native.rs:103-105, lib.rs:455-457
+    assert pa.calculate_scores(atts) == scores
+
+
+@pytest.mark.parametrize("nn,iters,seed", [(4, 20, 11), (4, 4, 12), (8, 3, 13)])
+def test_signed_attestation_lists_match_the_restatement(nn, iters, seed):
+    rng = random.Random(seed)
+    secrets = [rng.randrange(1, cref.SECP_N) for _ in range(nn - 1)]
+    addr = [cref.address_of(cref.public_key(s)) for s in secrets]
+    atts, who = [], []
+    for _ in range(2 * nn):
+        i, j = rng.sample(range(len(secrets)), 2)
+        atts.append(signed(secrets[i], addr[j], rng.randrange(1, 256), rng))
+        who.append(addr[i])
+    parts, want_fr, want_rat = expected_scores(atts, who, nn, iters, 1000)
+    fits = all(max(q.numerator, q.denominator).bit_length() <= 256 for q in want_rat[: len(parts)])
+    if not fits:
+        with pytest.raises(pa.EigenTrustError) as e:
+            pa.calculate_scores(atts, num_neighbours=nn, num_iterations=iters)
+        assert e.value.code == _ffi.ET_E_RATIONAL_TOO_LARGE
+        return
+    assert pa.recover_attesters(atts) == who
+    got, pub = pa.et_circuit_setup(atts, num_neighbours=nn, num_iterations=iters)
+    assert [g.address for g in got] == parts
+    for g, fr, q in zip(got, want_fr, want_rat):
+        assert int.from_bytes(g.score_fr, "big") == fr and g.rational == q
+    assert pub.scores == want_fr and pub.participants == [int.from_bytes(p, "big") for p in parts] + [0] * (nn - len(parts))
+    assert pa.calculate_scores(atts, who, num_neighbours=nn, num_iterations=iters) == got
