@@ -188,8 +188,12 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
 
     const uint64_t e0 = a.bk_ptr[b], e1 = a.bk_ptr[b + 1];
     constexpr int U = 4;
+    // Full batches of U * 1024 edges, the same number for every thread.  The hardware favours the
+    // oldest wavefront of a workgroup, which lets it run far ahead of the youngest; a barrier every
+    // second batch keeps all sixteen within one window of the source range.
+    const uint32_t n_batches = (uint32_t)((e1 - e0) / (U * 1024));
     uint64_t e = e0 + threadIdx.x;
-    for (; e + (U - 1) * 1024 < e1; e += U * 1024) {
+    for (uint32_t k = 0; k < n_batches; ++k, e += U * 1024) {
         uint32_t c[U];
         double w[U], xv[U];
         uint32_t r[U];
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
         for (int u = 0; u < U; ++u) xv[u] = xr[(size_t)(c[u] >> COL_SEG_SHIFT) * stride + (c[u] & COL_LOCAL_MASK)];
 #pragma unroll
         for (int u = 0; u < U; ++u) atomicAdd(&acc_l[r[u]], w[u] * xv[u]);
+        if (k & 1) __syncthreads();
     }
     for (; e < e1; e += 1024) {
         uint32_t c = a.col[e];
