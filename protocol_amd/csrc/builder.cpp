@@ -174,15 +174,16 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     {
         // f64 workgroups: one per CU unless the rows of a workgroup would not fit its LDS accumulators
         // (12288 rows plus the slack below stay under 160 KiB of f64 accumulators)
-        const uint32_t n_groups = geo.rows_cap / 64, rb_max = 12288;
+        const uint32_t n_groups = geo.rows_cap / BLOCK_GROUP, rb_max = 12288;
         uint32_t B = std::max<uint32_t>(1, std::min<uint32_t>(opt.f64_blocks ? opt.f64_blocks : 256, n_groups));
         B = std::max<uint32_t>(B, (geo.rows_cap + rb_max - 1) / rb_max);
         geo.f64_blocks = B;
         // a quarter more accumulator slots than an even deal needs: workgroups holding light rows
         // take more 64-row groups than those holding heavy ones
         const uint32_t even = (n_groups + B - 1) / B;
-        geo.f64_rb = (even + even / 4 + 2) * 64;
-        geo.nd_cap = std::max<uint32_t>(geo.nd_cap, (B + 15) / 16 * 16);
+        geo.f64_rb = (even + even / 4 + 2) * BLOCK_GROUP;
+        geo.f64_dblocks = dangling_blocks(B, geo.f64_rb / BLOCK_GROUP, geo.n_dangling_pad / BLOCK_GROUP / G);
+        geo.nd_cap = std::max<uint32_t>(geo.nd_cap, (geo.f64_dblocks + 15) / 16 * 16);
     }
     g.geo = geo;
     if (G > 8 || geo.seg_stride() >= COL_LOCAL_MASK) {
@@ -237,35 +238,46 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     g.nnz_local = in_ptr[geo.rows_cap];
     std::vector<uint32_t> e_src(g.nnz_local);   // source, encoded (segment << 29) | local row
     std::vector<uint64_t> e_idx(g.nnz_local);   // original edge index (for the value)
-    // the same edges grouped by f64 workgroup, ascending by source.  The 64-row groups are handed
-    // out heaviest first, each to the workgroup with the fewest edges so far that still has a free
-    // accumulator slot: the launch ends with its slowest workgroup, so edge counts must be level.
-    const uint32_t B = geo.f64_blocks, gpb = geo.f64_rb / 64, n_groups = geo.rows_cap / 64;
-    g.bk_grp.assign((size_t)B * gpb, 0xFFFFFFFFu);
-    std::vector<uint32_t> grp_block(n_groups), grp_slot(n_groups);
-    g.bk_ptr.assign((size_t)B + 1, 0);
-    {
-        std::vector<uint64_t> grp_edges(n_groups);
-        for (uint32_t gi = 0; gi < n_groups; ++gi) grp_edges[gi] = in_ptr[(size_t)gi * 64 + 64] - in_ptr[(size_t)gi * 64];
-        std::vector<uint32_t> by_weight(n_groups);
-        std::iota(by_weight.begin(), by_weight.end(), 0u);
-        std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t a, uint32_t b) { return grp_edges[a] > grp_edges[b]; });
-        typedef std::pair<uint64_t, uint32_t> Load;   // (edges so far, workgroup)
-        std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
-        for (uint32_t b = 0; b < B; ++b) heap.push(Load(0, b));
+    // The same edges grouped by workgroup of the f64 blocked sweep, ascending by source.  The row
+    // groups are handed out heaviest first, each to the workgroup with the fewest edges so far that
+    // still has a free accumulator slot: a launch ends with its slowest workgroup, so edge counts
+    // must be level.  Groups of dangling rows go first, to the leading `dblocks` workgroups.
+    const uint32_t n_groups = geo.rows_cap / BLOCK_GROUP, first_dangling_group = geo.n_active_pad / BLOCK_GROUP / G;
+    std::vector<uint64_t> grp_edges(n_groups);
+    for (uint32_t gi = 0; gi < n_groups; ++gi) grp_edges[gi] = in_ptr[(size_t)(gi + 1) * BLOCK_GROUP] - in_ptr[(size_t)gi * BLOCK_GROUP];
+    struct Deal { std::vector<uint32_t> block, slot; };
+    auto deal = [&](uint32_t B, uint32_t gpb, uint32_t dblocks, std::vector<uint32_t>& grp_table, std::vector<uint64_t>& ptr) {
+        Deal d;
+        d.block.assign(n_groups, 0);
+        d.slot.assign(n_groups, 0);
+        grp_table.assign((size_t)B * gpb, 0xFFFFFFFFu);
+        ptr.assign((size_t)B + 1, 0);
         std::vector<uint32_t> used(B, 0);
-        for (uint32_t gi : by_weight) {
-            Load l = heap.top();
-            heap.pop();
-            const uint32_t b = l.second;
-            grp_block[gi] = b;
-            grp_slot[gi] = used[b];
-            g.bk_grp[(size_t)b * gpb + used[b]] = gi;
-            g.bk_ptr[b + 1] += grp_edges[gi];
-            if (++used[b] < gpb) heap.push(Load(l.first + grp_edges[gi], b));   // a full workgroup leaves the heap
-        }
-    }
-    for (uint32_t b = 0; b < B; ++b) g.bk_ptr[b + 1] += g.bk_ptr[b];
+        std::vector<uint64_t> load(B, 0);
+        typedef std::pair<uint64_t, uint32_t> Load;   // (edges so far, workgroup)
+        auto pass = [&](uint32_t g0, uint32_t g1, uint32_t n_blocks) {
+            std::vector<uint32_t> by_weight(g1 - g0);
+            std::iota(by_weight.begin(), by_weight.end(), g0);
+            std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t x, uint32_t y) { return grp_edges[x] > grp_edges[y]; });
+            std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+            for (uint32_t bb = 0; bb < n_blocks; ++bb) if (used[bb] < gpb) heap.push(Load(load[bb], bb));
+            for (uint32_t gi : by_weight) {
+                Load l = heap.top();
+                heap.pop();
+                const uint32_t bb = l.second;
+                d.block[gi] = bb;
+                d.slot[gi] = used[bb];
+                grp_table[(size_t)bb * gpb + used[bb]] = gi;
+                load[bb] += grp_edges[gi];
+                if (++used[bb] < gpb) heap.push(Load(load[bb], bb));   // a full workgroup leaves the heap
+            }
+        };
+        pass(first_dangling_group, n_groups, dblocks);
+        pass(0, first_dangling_group, B);
+        for (uint32_t bb = 0; bb < B; ++bb) ptr[bb + 1] = ptr[bb] + load[bb];
+        return d;
+    };
+    const Deal d64 = deal(geo.f64_blocks, geo.f64_rb / BLOCK_GROUP, geo.f64_dblocks, g.bk_grp, g.bk_ptr);
     g.bk_col.resize(g.nnz_local);
     g.bk_row.resize(g.nnz_local);
     if (g.values_are_u32) g.bk_val_u32.resize(g.nnz_local);
@@ -287,10 +299,10 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
                 uint64_t p = cur[lr]++;
                 e_src[p] = pf;
                 e_idx[p] = kept[k];
-                const uint32_t grp = lr >> 6;
-                uint64_t q = bcur[grp_block[grp]]++;
+                const uint32_t grp = lr / BLOCK_GROUP;
+                uint64_t q = bcur[d64.block[grp]]++;
                 g.bk_col[q] = pf;
-                g.bk_row[q] = (uint16_t)(grp_slot[grp] * 64 + (lr & 63));
+                g.bk_row[q] = (uint16_t)(d64.slot[grp] * BLOCK_GROUP + lr % BLOCK_GROUP);
                 if (g.values_are_u32) g.bk_val_u32[q] = in.val_u32[kept[k]];
                 else g.bk_val_fr[q] = in.val_fr[kept[k]];
             }

@@ -57,7 +57,7 @@ struct HostGraph {
     // f64 variant ("blocked sweep"): per workgroup b the edges of its rows, ascending by source
     // position; entries bk_ptr[b] .. bk_ptr[b+1].
     std::vector<uint64_t> bk_ptr;
-    // bk_grp[b * (f64_rb / 64) + j]: the 64-row group whose accumulators are slot j of workgroup b, or ~0
+    // bk_grp[b * (f64_rb / BLOCK_GROUP) + j]: the row group whose accumulators are slot j of workgroup b, or ~0
     std::vector<uint32_t> bk_grp;
     std::vector<uint32_t> bk_col;       // source, (segment << 29) | local row
     std::vector<uint16_t> bk_row;       // row inside the workgroup's accumulator array

@@ -128,7 +128,7 @@ ET_DEV double wave_sum_f64(double v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// f64 variant, "blocked sweep".  One 1024-thread workgroup per CU owns up to geo.f64_rb rows (64-row
+// f64 variant, "blocked sweep".  One 1024-thread workgroup per CU owns up to geo.f64_rb rows (row
 // groups handed out so that every workgroup gets the same number of edges) with their accumulators in
 // LDS, and walks its edges in ascending SOURCE order: the edge records stream in coalesced, each
 // edge costs one 8-byte gather and one LDS atomic add.  Because every workgroup sweeps the source
@@ -142,7 +142,7 @@ ET_DEV double wave_sum_f64(double v) {
 // ---------------------------------------------------------------------------------------------
 struct StepArgsF64B {
     const uint64_t* bk_ptr;
-    const uint32_t* grp;      // [f64_blocks][f64_rb / 64] 64-row group behind each accumulator slot, ~0 = none
+    const uint32_t* grp;      // [f64_blocks][f64_rb / BLOCK_GROUP] row group behind each run of accumulator slots, ~0 = none
     const uint32_t* col;
     const void* w;            // VT per edge
     const uint16_t* row;
@@ -214,10 +214,10 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
 
     double res = 0.0, tot = 0.0, dacc = 0.0;
     for (uint32_t lr = threadIdx.x; lr < RB; lr += 1024) {
-        const uint32_t grp = a.grp[(size_t)b * (RB >> 6) + (lr >> 6)];
+        const uint32_t grp = a.grp[(size_t)b * (RB / BLOCK_GROUP) + lr / BLOCK_GROUP];
         if (grp == 0xFFFFFFFFu) continue;
-        const uint32_t row = grp * 64 + (lr & 63);
-        const uint64_t q = ((uint64_t)grp * a.geo.n_seg + a.geo.seg) * 64 + (lr & 63);
+        const uint32_t row = grp * BLOCK_GROUP + lr % BLOCK_GROUP;
+        const uint64_t q = ((uint64_t)(row >> 6) * a.geo.n_seg + a.geo.seg) * 64 + (row & 63);
         const bool active = q < a.geo.n_active;
         const bool dang = q >= a.geo.n_active_pad && q < (uint64_t)a.geo.n_active_pad + a.geo.n_dangling;
         if (!active && !dang) continue;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
         for (int w = 0; w < 16; ++w) { r += red[0][w]; t += red[1][w]; d += red[2][w]; }
         a.res_part[b] = r;
         a.sum_part[b] = t;
-        a.y[my_base + a.geo.rows_cap + b] = d;   // partial sum slot b of this segment (nd_cap >= f64_blocks)
+        if (b < a.geo.f64_dblocks) a.y[my_base + a.geo.rows_cap + b] = d;   // partial sum slot b of this segment
     }
 }
 

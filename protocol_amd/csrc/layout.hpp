@@ -45,6 +45,17 @@ struct WorkDesc {
 static const uint32_t WORK_DANGLING = 1u;
 
 // A source index in the edge stream: segment in the top 3 bits, local row below.
+// Rows are handed to the workgroups of a blocked sweep in groups of BLOCK_GROUP consecutive rows (position
+// order is degree order, so the heaviest rows sit together: small groups keep the heaviest group well
+// below a workgroup's share of the edges).
+static const uint32_t BLOCK_GROUP = 16;
+// workgroups of a blocked sweep that may hold dangling rows: the first 256, or as many as it takes for the
+// dangling groups to fill at most half of their accumulator slots
+inline uint32_t dangling_blocks(uint32_t blocks, uint32_t groups_per_block, uint32_t dangling_groups) {
+    uint32_t need = (uint32_t)(((uint64_t)dangling_groups * 2 + groups_per_block - 1) / groups_per_block);
+    uint32_t d = need > 256 ? need : 256;
+    return d < blocks ? d : blocks;
+}
 static const uint32_t COL_SEG_SHIFT = 29;
 static const uint32_t COL_LOCAL_MASK = (1u << COL_SEG_SHIFT) - 1;
 
@@ -61,9 +72,12 @@ struct Geometry {
     // The first hot_* local rows of every segment hold the most frequently gathered sources; the
     // step kernels keep them in LDS (per variant, because the entry size differs).
     uint32_t hot_f64, hot_fr;
-    // f64 variant: the segment's 64-row groups are dealt round-robin to f64_blocks workgroups, each
-    // of which keeps f64_rb row accumulators in LDS and walks its edges in ascending source order.
+    // f64 blocked sweep: the segment's BLOCK_GROUP-row groups are handed to f64_blocks workgroups, each
+    // of which keeps up to f64_rb row accumulators in LDS and walks its edges in ascending source order.
     uint32_t f64_blocks, f64_rb;
+    // groups of dangling rows go to the first f64_dblocks workgroups only; workgroup b of those writes
+    // partial-sum slot b of its segment, so nd_cap >= f64_dblocks
+    uint32_t f64_dblocks;
     ET_HD uint32_t seg_stride() const { return rows_cap + nd_cap; }
     ET_HD uint32_t pos_of_col(uint32_t c) const { return (c >> COL_SEG_SHIFT) * seg_stride() + (c & COL_LOCAL_MASK); }
 };
