@@ -154,3 +154,66 @@ def test_insufficient_peers_is_an_error():
     with pytest.raises(pa.EigenTrustError) as ei:
         s.converge()   # native.rs:484-510 test_one_member_converge
     assert ei.value.code == pa._ffi.ET_E_INSUFFICIENT_PEERS
+
+
+@pytest.mark.parametrize("iters", [0, 1, 2, 7])
+def test_iteration_counts_including_zero(iters):
+    rng = np.random.default_rng(40 + iters)
+    n = 900
+    member, frm, to, val = random_graph(rng, n, 6, 0.1, 0.1, 255)
+    g = pa.Graph(n, frm, to, value_u32=val, member=member)
+    rc, exp, _, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000)
+    assert rc == 0
+    assert np.array_equal(g.converge_fr(iters, 1000), exp)
+    rc, _e, eld, _r, _, _ = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000.0, want_ld=True)
+    o64, _ = g.converge_f64(iters, 1000.0)
+    assert rel_l1(o64, eld) <= F64_TOL
+    if iters == 0:   # native.rs:317: the initial scores, zero for empty slots
+        assert pa.fr_ints_from_bytes(g.converge_fr(0, 1000)) == [1000 if m else 0 for m in member]
+    # the same graph object serves converge after converge (native.rs:873-878 calls converge repeatedly)
+    assert np.array_equal(g.converge_fr(iters, 1000), exp)
+
+
+def test_no_attestations_at_all():
+    # every member is dangling: each gives 1 to every other member (native.rs:263-278), scores stay put
+    n = 70
+    member = np.ones(n, dtype=np.uint8)
+    member[[3, 69]] = 0
+    g = pa.Graph(n, [], [], value_u32=[], member=member)
+    assert pa.fr_ints_from_bytes(g.converge_fr(20, 1000)) == [1000 if m else 0 for m in member]
+    o64, res = g.converge_f64(20, 1000.0)
+    assert np.allclose(o64, 1000.0 * member, rtol=1e-12) and res < 1e-6
+
+
+def test_one_row_receives_every_attestation():
+    # a single destination row far longer than any workgroup's share of an even deal
+    n = 60000
+    frm = np.arange(1, n, dtype=np.uint32)
+    to = np.zeros(n - 1, dtype=np.uint32)
+    val = (np.arange(n - 1, dtype=np.uint32) % 255) + 1
+    member = np.ones(n, dtype=np.uint8)
+    rc, exp, _, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=5, initial=1000)
+    assert rc == 0
+    g = pa.Graph(n, frm, to, value_u32=val, member=member)
+    assert np.array_equal(g.converge_fr(5, 1000), exp)
+    rc, _e, eld, _r, _, _ = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=5, initial=1000.0, want_ld=True)
+    o64, _ = g.converge_f64(5, 1000.0)
+    assert rel_l1(o64, eld) <= F64_TOL
+
+
+def test_full_size_benchmark_graph_parity():
+    """The graph the metric is quoted on (1M peers / 16M attestations, 20 iterations), whole result:
+    exact variant bit for bit against the C restatement, f64 against its long-double restatement."""
+    n = 1 << 20
+    frm, to, val = pa.synth_graph(3, n, 1 << 24, seed=42, value_max=255)
+    member = np.ones(n, dtype=np.uint8)
+    g = pa.Graph(n, frm, to, value_u32=val, member=member)
+    rc, exp, nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=20, initial=1000,
+                                                  n_threads=c_oracle.max_threads())
+    assert rc == 0 and nnz == g.info.nnz == 1 << 24
+    out = g.converge_fr(20, 1000)
+    assert hashlib.sha256(out.tobytes()).hexdigest() == hashlib.sha256(exp.tobytes()).hexdigest()
+    rc, _e, eld, _r, _, _ = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=20, initial=1000.0,
+                                                         n_threads=c_oracle.max_threads(), want_ld=True)
+    o64, _ = g.converge_f64(20, 1000.0)
+    assert rel_l1(o64, eld) <= F64_TOL
