@@ -197,7 +197,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
             "dtype": "f64" if "f64" in results else "fr254", "data": "synthetic",
-            "config": {"workload": "%s: %s; %d iterations per step; pre-normalised weights" % (wl, desc, NUM_ITER),
+            "config": {"workload": "%s: %s; %d iterations per step; byte opinions kept raw in the edge records" % (wl, desc, NUM_ITER),
                        "peers": n, "edges": nnz, "iterations": NUM_ITER, "parallelism": "rows sharded x%d" % world,
                        "seed": args.seed},
             "roofline": head["roofline"],
