@@ -4,6 +4,8 @@
 #include <cstring>
 #include <numeric>
 #include <queue>
+#include <thread>
+#include <cstdlib>
 
 #include "../../include/eigentrust_hip.h"
 
@@ -21,6 +23,22 @@ struct Pos {  // global sorted row -> (segment, local row, position)
 };
 
 }  // namespace
+
+// host threads for the scatter passes of the builder (the GPU boxes give a process 16 CPUs)
+static unsigned host_threads() {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned t = std::max(1u, std::min(16u, hw ? hw : 1u));
+    if (const char* e = getenv("ET_BUILD_THREADS")) t = (unsigned)std::max(1, atoi(e));
+    return t;
+}
+template <typename F>
+static void run_threads(unsigned count, F f) {
+    if (count <= 1) { f(0); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < count; ++t) th.emplace_back([&f, t]() { f(t); });
+    f(0);
+    for (auto& x : th) x.join();
+}
 
 int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::string& err) {
     const uint32_t n = in.n;
@@ -201,19 +219,24 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     g.scale_fr.assign(vec_len, FrRaw{{0, 0, 0, 0}});
     g.scale_f64.assign(vec_len, 0.0);
     {
-        std::vector<Fr> inv(n_active);
-        for (uint32_t r = 0; r < n_active; ++r) {
-            uint32_t i = order[r];
-            inv[r] = g.values_are_u32 ? Fr::from_u64(sum_u64[i]) : sum_fr[i];
-        }
-        fr_batch_invert(inv);  // native.rs:308
+        // native.rs:308, one batch inversion per host thread over its share of the active peers
         const Fr two576 = Fr::one().pow2k(576);
-        for (uint32_t r = 0; r < n_active; ++r) {
-            uint32_t i = order[r];
-            uint32_t p = g.pos_of_ext[i];
-            g.scale_fr[p] = (inv[r] * two576).to_raw();
-            g.scale_f64[p] = g.values_are_u32 ? 1.0 / (double)sum_u64[i] : (double)(1.0L / sum_ld[i]);
-        }
+        const unsigned T6 = host_threads();
+        run_threads(T6, [&](unsigned t) {
+            const uint32_t r0 = (uint32_t)((uint64_t)n_active * t / T6), r1 = (uint32_t)((uint64_t)n_active * (t + 1) / T6);
+            std::vector<Fr> inv(r1 - r0);
+            for (uint32_t r = r0; r < r1; ++r) {
+                uint32_t i = order[r];
+                inv[r - r0] = g.values_are_u32 ? Fr::from_u64(sum_u64[i]) : sum_fr[i];
+            }
+            fr_batch_invert(inv);
+            for (uint32_t r = r0; r < r1; ++r) {
+                uint32_t i = order[r];
+                uint32_t p = g.pos_of_ext[i];
+                g.scale_fr[p] = (inv[r - r0] * two576).to_raw();
+                g.scale_f64[p] = g.values_are_u32 ? 1.0 / (double)sum_u64[i] : (double)(1.0L / sum_ld[i]);
+            }
+        });
         g.inv_nm1_w = (Fr::from_u64(n_valid - 1).invert_or_zero() * Fr::one().pow2k(288)).to_raw();
     }
 
@@ -225,15 +248,26 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         if (p < my_base || p >= my_base + geo.rows_cap) return 0xFFFFFFFFu;
         return p - my_base;
     };
+    // The passes below scatter every surviving edge by destination row; they run on several host
+    // threads, each owning a contiguous range of rows (or of workgroups), so that no two threads
+    // write the same counter and every thread emits its edges in the same, source-ascending order.
+    const unsigned T = host_threads();
+    const uint64_t n_kept = out_ptr[n];
+    std::vector<uint32_t> lr_of_edge(n_kept);   // local row of edge k's destination, ~0 = dropped or another segment's
+    run_threads(T, [&](unsigned t) {
+        for (uint64_t k = n_kept * t / T; k < n_kept * (t + 1) / T; ++k) lr_of_edge[k] = drop[k] ? 0xFFFFFFFFu : local_row(in.to[kept[k]]);
+    });
     std::vector<uint64_t> in_ptr((size_t)geo.rows_cap + 1, 0);
-    for (uint32_t f = 0; f < n; ++f) {
-        if (dangling[f]) continue;
-        for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
-            if (drop[k]) continue;
-            uint32_t lr = local_row(in.to[kept[k]]);
-            if (lr != 0xFFFFFFFFu) in_ptr[lr + 1]++;
+    run_threads(T, [&](unsigned t) {
+        const uint32_t r0 = (uint32_t)((uint64_t)geo.rows_cap * t / T), r1 = (uint32_t)((uint64_t)geo.rows_cap * (t + 1) / T);
+        for (uint32_t f = 0; f < n; ++f) {
+            if (dangling[f]) continue;
+            for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
+                const uint32_t lr = lr_of_edge[k];
+                if (lr >= r0 && lr < r1) in_ptr[lr + 1]++;
+            }
         }
-    }
+    });
     for (uint32_t i = 0; i < geo.rows_cap; ++i) in_ptr[i + 1] += in_ptr[i];
     g.nnz_local = in_ptr[geo.rows_cap];
     std::vector<uint32_t> e_src(g.nnz_local);   // source, encoded (segment << 29) | local row
@@ -289,24 +323,43 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         std::vector<uint64_t> bcur(g.bk_ptr.begin(), g.bk_ptr.end() - 1);
         std::vector<uint32_t> by_pos(order.begin(), order.begin() + n_active);
         std::sort(by_pos.begin(), by_pos.end(), [&](uint32_t a, uint32_t b) { return g.pos_of_ext[a] < g.pos_of_ext[b]; });
-        for (uint32_t f : by_pos) {
-            uint32_t pf = g.pos_of_ext[f];
-            pf = ((pf / geo.seg_stride()) << COL_SEG_SHIFT) | (pf % geo.seg_stride());
-            for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
-                if (drop[k]) continue;
-                uint32_t lr = local_row(in.to[kept[k]]);
-                if (lr == 0xFFFFFFFFu) continue;
-                uint64_t p = cur[lr]++;
-                e_src[p] = pf;
-                e_idx[p] = kept[k];
-                const uint32_t grp = lr / BLOCK_GROUP;
-                uint64_t q = bcur[d64.block[grp]]++;
-                g.bk_col[q] = pf;
-                g.bk_row[q] = (uint16_t)(d64.slot[grp] * BLOCK_GROUP + lr % BLOCK_GROUP);
-                if (g.values_are_u32) g.bk_val_u32[q] = in.val_u32[kept[k]];
-                else g.bk_val_fr[q] = in.val_fr[kept[k]];
+        // (a) per-row lists: thread t owns the rows whose edges fall in its share of the edge count
+        std::vector<uint32_t> row_cut(T + 1, geo.rows_cap);
+        row_cut[0] = 0;
+        for (unsigned t = 1; t < T; ++t)
+            row_cut[t] = (uint32_t)(std::lower_bound(in_ptr.begin(), in_ptr.end(), g.nnz_local * t / T) - in_ptr.begin());
+        for (unsigned t = 1; t <= T; ++t) row_cut[t] = std::max(row_cut[t], row_cut[t - 1]);
+        row_cut[T] = geo.rows_cap;
+        // (b) per-workgroup lists: thread t owns a contiguous range of workgroups
+        const uint32_t B64 = geo.f64_blocks;
+        run_threads(2 * T, [&](unsigned tt) {
+            const bool rows_pass = tt < T;
+            const unsigned t = rows_pass ? tt : tt - T;
+            const uint32_t r0 = row_cut[t], r1 = row_cut[t + 1];
+            const uint32_t b0 = (uint32_t)((uint64_t)B64 * t / T), b1 = (uint32_t)((uint64_t)B64 * (t + 1) / T);
+            for (uint32_t f : by_pos) {
+                uint32_t pf = g.pos_of_ext[f];
+                pf = ((pf / geo.seg_stride()) << COL_SEG_SHIFT) | (pf % geo.seg_stride());
+                for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
+                    const uint32_t lr = lr_of_edge[k];
+                    if (lr == 0xFFFFFFFFu) continue;
+                    if (rows_pass) {
+                        if (lr < r0 || lr >= r1) continue;
+                        uint64_t p = cur[lr]++;
+                        e_src[p] = pf;
+                        e_idx[p] = kept[k];
+                    } else {
+                        const uint32_t grp = lr / BLOCK_GROUP, blk = d64.block[grp];
+                        if (blk < b0 || blk >= b1) continue;
+                        uint64_t q = bcur[blk]++;
+                        g.bk_col[q] = pf;
+                        g.bk_row[q] = (uint16_t)(d64.slot[grp] * BLOCK_GROUP + lr % BLOCK_GROUP);
+                        if (g.values_are_u32) g.bk_val_u32[q] = in.val_u32[kept[k]];
+                        else g.bk_val_fr[q] = in.val_fr[kept[k]];
+                    }
+                }
             }
-        }
+        });
     }
     // ---- 8. slices -----------------------------------------------------------------------------
     const uint32_t long_row = opt.long_row ? opt.long_row : 128;
@@ -353,7 +406,10 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     g.col.assign(slots, 0);
     if (g.values_are_u32) g.val_u32.assign(slots, 0);
     else g.val_fr.assign(slots, FrRaw{{0, 0, 0, 0}});
-    for (const SliceDesc& sd : g.slices) {
+    run_threads(T, [&](unsigned t) {
+      const size_t s0 = g.slices.size() * t / T, s1 = g.slices.size() * (t + 1) / T;
+      for (size_t si = s0; si < s1; ++si) {   // slices own disjoint slots
+        const SliceDesc& sd = g.slices[si];
         if (sd.nrows & SLICE_REDUCE) {
             uint64_t b = in_ptr[sd.row0], e = in_ptr[sd.row0 + 1];
             for (uint64_t k = b; k < e; ++k) {
@@ -373,7 +429,8 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
                 }
             }
         }
-    }
+      }
+    });
     // ---- 10. wavefront work items: contiguous, class-pure, equal estimated cost ------------------
     const uint32_t n_slices = (uint32_t)g.slices.size();
     uint32_t first_dang = n_slices;
