@@ -378,8 +378,20 @@ int et_attestation_hash(const et_attestation *att, et_fr *out);
  * public_keys = n*64 bytes or NULL.  ET_E_BAD_SIGNATURE where the reference unwraps or asserts. */
 int et_attestations_recover(const et_attestation *atts, size_t n, uint8_t *attesters,
                             uint8_t *public_keys);
+/* The same on the GPU, one lane per record (Poseidon, the curve arithmetic and Keccak in one kernel): for set
+ * building at scale.  Results are identical to et_attestations_recover.  device < 0: the current device. */
+int et_attestations_recover_gpu(const et_attestation *atts, size_t n, uint8_t *attesters,
+                                uint8_t *public_keys, int device);
+/* Self-test hook: the lane function of that kernel compiled for the host, on one record, so that the device
+ * arithmetic can be checked where no GPU is present.  Not a compute path. */
+int et_attestation_recover_lane_host(const et_attestation *att, uint8_t attester[20],
+                                     uint8_t public_key[64]);
 /* secret * G and its Ethereum address (ecdsa/native.rs:254-262, :90-111); for tests and tools. */
 int et_secp256k1_public_key(const uint8_t secret_le[32], uint8_t public_key[64], uint8_t address[20]);
+/* EcdsaKeypair::sign with the caller's nonce (ecdsa/native.rs:264-296): r, s little-endian, rec_id = parity of
+ * the nonce point's y.  For tests and tools that need signed records. */
+int et_secp256k1_sign(const uint8_t secret_le[32], const et_fr *msg_hash, const uint8_t nonce_le[32],
+                      uint8_t sig_r[32], uint8_t sig_s[32], uint8_t *rec_id);
 /* Opinion::validate (opinion/native.rs:63-109) for one attester: atts has num_neighbours records,
  * present[i] == 0 (or a NULL `present` = all present) marks an entry the reference fills with
  * empty_with_about (dynamic_sets/native.rs:209-219); set_addresses = num_neighbours * 20 bytes,

@@ -157,7 +157,10 @@ PROTOTYPES = {
     "et_keccak256": (i32, [vp, C.c_size_t, vp]),
     "et_attestation_hash": (i32, [P(EtAttestation), vp]),
     "et_attestations_recover": (i32, [P(EtAttestation), C.c_size_t, vp, vp]),
+    "et_attestations_recover_gpu": (i32, [P(EtAttestation), C.c_size_t, vp, vp, i32]),
+    "et_attestation_recover_lane_host": (i32, [P(EtAttestation), vp, vp]),
     "et_secp256k1_public_key": (i32, [vp, vp, vp]),
+    "et_secp256k1_sign": (i32, [vp, vp, vp, vp, vp, vp]),
     "et_opinion_validate": (i32, [vp, P(EtAttestation), vp, vp, u32, vp, vp, vp]),
     "et_et_setup": (i32, [P(EtAttestation), C.c_size_t, vp, u32, u32, u64, u64, P(EtScore), C.c_size_t, P(C.c_size_t), vp, C.c_size_t]),
     "et_local_scores": (i32, [P(EtAttestation), vp, C.c_size_t, vp, u32, u32, u64, u64, P(EtScore), C.c_size_t, P(C.c_size_t)]),

@@ -1,0 +1,492 @@
+// Batched attester recovery on the GPU: one lane per signed attestation record.
+//
+// What the reference does once per record while it builds the participant set
+// (eigentrust/src/lib.rs:351-358 -> attestation.rs:215-239):
+//   hash   = Poseidon5(about, domain, value, message, 0)[0]              (dynamic_sets/native.rs:96-104)
+//   R      = the curve point with x = r and the parity rec_id            (ecdsa/native.rs:307-316)
+//   Q      = r^-1 * (s * R - hash * G)                                   (ecdsa/native.rs:318-320)
+//   address = last 20 bytes of Keccak-256(x(Q) || y(Q)), big-endian       (ecdsa/native.rs:90-111, eth.rs:70-74)
+// The host path (crypto.cpp) does the same per record on CPU threads and is what small sets use; this
+// kernel is for set building at scale.  By construction Q satisfies the verification equation
+// x(hash/s * G + r/s * Q) = r whenever it is not the point at infinity, so the sanity check of
+// ecdsa/native.rs:322-327 cannot fail here and is not repeated per lane.
+//
+// All three prime fields (secp256k1 base field p, its scalar field n, bn256 scalar field) use one
+// Montgomery multiplication over 8 x 32-bit limbs with R = 2^256; the moduli live in constant memory.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/eigentrust_hip.h"
+#include "crypto.hpp"
+#include "engine.hpp"
+#include "fr_host.hpp"
+#include "mont256.hpp"
+
+namespace et {
+
+#define HIP_TRY_E(expr)                                                               \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));             \
+            return _e == hipErrorNoDevice ? ET_E_NO_DEVICE : ET_E_HIP;                \
+        }                                                                             \
+    } while (0)
+
+struct F256 {
+    uint32_t v[8];
+};
+struct ModConst {
+    uint32_t m[8];     // modulus
+    uint32_t r2[8];    // 2^512 mod m
+    uint32_t one[8];   // 2^256 mod m
+    uint32_t n0;       // -m^-1 mod 2^32
+    uint32_t pad[7];
+};
+enum { MOD_P = 0, MOD_N = 1, MOD_R = 2 };
+
+struct RecoverConsts {
+    ModConst mod[3];
+    F256 gx, gy;          // generator, Montgomery form mod p
+    F256 seven;           // 7, Montgomery form mod p
+    F256 rc[340];         // Poseidon round constants, Montgomery form mod r
+    F256 mds[25];
+};
+
+#define EC_DEV __host__ __device__ __forceinline__
+
+EC_DEV bool f_is_zero(const F256& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= a.v[i];
+    return o == 0;
+}
+EC_DEV bool f_eq(const F256& a, const F256& b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+}
+EC_DEV bool f_geq(const F256& a, const uint32_t* m) {   // a >= m
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t d = (uint64_t)a.v[i] - m[i] - br;
+        br = (d >> 32) & 1;
+    }
+    return br == 0;
+}
+EC_DEV F256 f_sub_raw(const F256& a, const uint32_t* m) {
+    F256 r;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t d = (uint64_t)a.v[i] - m[i] - br;
+        r.v[i] = (uint32_t)d;
+        br = (d >> 32) & 1;
+    }
+    return r;
+}
+EC_DEV F256 f_add(const F256& a, const F256& b, const ModConst& M) {
+    F256 r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t t = (uint64_t)a.v[i] + b.v[i] + c;
+        r.v[i] = (uint32_t)t;
+        c = t >> 32;
+    }
+    if (c || f_geq(r, M.m)) r = f_sub_raw(r, M.m);
+    return r;
+}
+EC_DEV F256 f_sub(const F256& a, const F256& b, const ModConst& M) {
+    F256 r;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t d = (uint64_t)a.v[i] - b.v[i] - br;
+        r.v[i] = (uint32_t)d;
+        br = (d >> 32) & 1;
+    }
+    if (br) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint64_t t = (uint64_t)r.v[i] + M.m[i] + c;
+            r.v[i] = (uint32_t)t;
+            c = t >> 32;
+        }
+    }
+    return r;
+}
+// Montgomery product a * b * 2^-256 mod m (coarsely integrated operand scanning)
+EC_DEV F256 f_mul(const F256& a, const F256& b, const ModConst& M) {
+    uint32_t t[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t v = (uint64_t)a.v[j] * b.v[i] + t[j] + c;
+            t[j] = (uint32_t)v;
+            c = v >> 32;
+        }
+        uint64_t v = (uint64_t)t[8] + c;
+        t[8] = (uint32_t)v;
+        t[9] = (uint32_t)(v >> 32);
+        const uint32_t q = t[0] * M.n0;
+        v = (uint64_t)q * M.m[0] + t[0];
+        c = v >> 32;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            v = (uint64_t)q * M.m[j] + t[j] + c;
+            t[j - 1] = (uint32_t)v;
+            c = v >> 32;
+        }
+        v = (uint64_t)t[8] + c;
+        t[7] = (uint32_t)v;
+        t[8] = t[9] + (uint32_t)(v >> 32);
+    }
+    F256 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = t[i];
+    if (t[8] || f_geq(r, M.m)) r = f_sub_raw(r, M.m);
+    return r;
+}
+EC_DEV F256 f_load_mod(const uint32_t* p) {
+    F256 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = p[i];
+    return r;
+}
+EC_DEV F256 f_to_mont(const F256& a, const ModConst& M) { return f_mul(a, f_load_mod(M.r2), M); }
+EC_DEV F256 f_from_mont(const F256& a, const ModConst& M) {
+    F256 one;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) one.v[i] = i == 0 ? 1u : 0u;
+    return f_mul(a, one, M);
+}
+// a^(m - k) for a small k: k = 2 is the inverse (Fermat), (m + 1) / 4 is handled by the caller's exponent
+EC_DEV F256 f_pow(const F256& a, const F256& e, const ModConst& M) {
+    F256 r = f_load_mod(M.one);
+    for (int i = 255; i >= 0; --i) {
+        r = f_mul(r, r, M);
+        if ((e.v[i >> 5] >> (i & 31)) & 1) r = f_mul(r, a, M);
+    }
+    return r;
+}
+EC_DEV F256 f_inv(const F256& a, const ModConst& M) {
+    F256 e = f_load_mod(M.m);   // m - 2: the moduli here all end in ...1 or ...f, so no borrow past limb 0
+    e.v[0] -= 2;
+    return f_pow(a, e, M);
+}
+
+// Jacobian points on y^2 = x^3 + 7 over F_p, Montgomery coordinates; z == 0 is the point at infinity
+struct JPt {
+    F256 x, y, z;
+};
+EC_DEV JPt j_double(const JPt& p, const ModConst& P) {
+    if (f_is_zero(p.z) || f_is_zero(p.y)) { JPt o = p; for (int i = 0; i < 8; ++i) o.z.v[i] = 0; return o; }
+    F256 a = f_mul(p.x, p.x, P), b = f_mul(p.y, p.y, P), c = f_mul(b, b, P);
+    F256 t = f_add(p.x, b, P);
+    F256 d = f_sub(f_sub(f_mul(t, t, P), a, P), c, P);
+    d = f_add(d, d, P);
+    F256 e = f_add(f_add(a, a, P), a, P), f = f_mul(e, e, P);
+    JPt r;
+    r.x = f_sub(f, f_add(d, d, P), P);
+    F256 c8 = f_add(c, c, P);
+    c8 = f_add(c8, c8, P);
+    c8 = f_add(c8, c8, P);
+    r.y = f_sub(f_mul(e, f_sub(d, r.x, P), P), c8, P);
+    F256 yz = f_mul(p.y, p.z, P);
+    r.z = f_add(yz, yz, P);
+    return r;
+}
+// p + (qx, qy) with the second point affine
+EC_DEV JPt j_add_affine(const JPt& p, const F256& qx, const F256& qy, const ModConst& P) {
+    if (f_is_zero(p.z)) {
+        JPt o;
+        o.x = qx; o.y = qy; o.z = f_load_mod(P.one);
+        return o;
+    }
+    F256 z1z1 = f_mul(p.z, p.z, P);
+    F256 u2 = f_mul(qx, z1z1, P), s2 = f_mul(f_mul(qy, p.z, P), z1z1, P);
+    if (f_eq(p.x, u2)) {
+        if (f_eq(p.y, s2)) return j_double(p, P);
+        JPt o = p;
+        for (int i = 0; i < 8; ++i) o.z.v[i] = 0;
+        return o;
+    }
+    F256 h = f_sub(u2, p.x, P), r = f_sub(s2, p.y, P);
+    F256 hh = f_mul(h, h, P), hhh = f_mul(hh, h, P), v = f_mul(p.x, hh, P);
+    JPt o;
+    o.x = f_sub(f_sub(f_mul(r, r, P), hhh, P), f_add(v, v, P), P);
+    o.y = f_sub(f_mul(r, f_sub(v, o.x, P), P), f_mul(p.y, hhh, P), P);
+    o.z = f_mul(p.z, h, P);
+    return o;
+}
+
+EC_DEV uint64_t rol64(uint64_t v, int n) { return (v << n) | (v >> (64 - n)); }
+EC_DEV void keccak_f1600(uint64_t s[25]) {
+    const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+                             0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+                             0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+                             0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+                             0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+                             0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    for (int round = 0; round < 24; ++round) {
+        uint64_t c[5], d[5], b[25];
+#pragma unroll
+        for (int x = 0; x < 5; ++x) c[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
+#pragma unroll
+        for (int x = 0; x < 5; ++x) d[x] = c[(x + 4) % 5] ^ rol64(c[(x + 1) % 5], 1);
+#pragma unroll
+        for (int i = 0; i < 25; ++i) s[i] ^= d[i % 5];
+#pragma unroll
+        for (int x = 0; x < 5; ++x)
+#pragma unroll
+            for (int y = 0; y < 5; ++y) {
+                const int rot = ROT[x + 5 * y];
+                b[y + 5 * ((2 * x + 3 * y) % 5)] = rot ? rol64(s[x + 5 * y], rot) : s[x + 5 * y];
+            }
+#pragma unroll
+        for (int y = 0; y < 5; ++y)
+#pragma unroll
+            for (int x = 0; x < 5; ++x) s[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        s[0] ^= RC[round];
+    }
+}
+
+EC_DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+// status codes per record
+enum { REC_OK = 0, REC_BAD_SCALAR = 1, REC_NOT_ON_CURVE = 2, REC_INFINITY = 3 };
+
+EC_DEV void recover_lane(const uint8_t* rec, const RecoverConsts* K, uint8_t* out, uint32_t* ko, uint8_t* status_out) {
+    const ModConst& P = K->mod[MOD_P];
+    const ModConst& N = K->mod[MOD_N];
+    const ModConst& R = K->mod[MOD_R];
+
+    // ---- attestation hash: Poseidon over (about, domain, value, message, 0) ----------------------------
+    F256 st[5];
+    {
+        F256 about, domain, value, message;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) about.v[k] = domain.v[k] = value.v[k] = message.v[k] = 0;
+        for (int b = 0; b < 20; ++b) {   // the address bytes reversed are the low 20 bytes of the scalar (eth.rs:77-95)
+            about.v[b >> 2] |= (uint32_t)rec[19 - b] << (8 * (b & 3));
+            domain.v[b >> 2] |= (uint32_t)rec[20 + 19 - b] << (8 * (b & 3));
+        }
+        value.v[0] = rec[40];
+        for (int b = 0; b < 32; ++b) message.v[b >> 2] |= (uint32_t)rec[41 + 31 - b] << (8 * (b & 3));
+        // the message is a 256-bit big-endian integer reduced mod r (attestation.rs:107-113): at most five subtractions
+        for (int k = 0; k < 6; ++k) if (f_geq(message, R.m)) message = f_sub_raw(message, R.m);
+        st[0] = f_to_mont(about, R); st[1] = f_to_mont(domain, R); st[2] = f_to_mont(value, R); st[3] = f_to_mont(message, R);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st[4].v[k] = 0;
+    }
+    for (int round = 0; round < 68; ++round) {   // poseidon/native/mod.rs:34-97: 4 full, 60 partial, 4 full
+        const bool full = round < 4 || round >= 64;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) st[k] = f_add(st[k], K->rc[round * 5 + k], R);
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { F256 x2 = f_mul(st[k], st[k], R); st[k] = f_mul(f_mul(x2, x2, R), st[k], R); }
+        } else {
+            F256 x2 = f_mul(st[0], st[0], R);
+            st[0] = f_mul(f_mul(x2, x2, R), st[0], R);
+        }
+        F256 o[5];
+        for (int a = 0; a < 5; ++a) {
+            F256 acc = f_mul(K->mds[a * 5], st[0], R);
+            for (int b = 1; b < 5; ++b) acc = f_add(acc, f_mul(K->mds[a * 5 + b], st[b], R), R);
+            o[a] = acc;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) st[k] = o[k];
+    }
+    F256 hash = f_from_mont(st[0], R);   // < r < n: usable as a secp256k1 scalar as it is (attestation.rs:225-233)
+
+    // ---- signature scalars ------------------------------------------------------------------------
+    F256 r, s;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { r.v[k] = 0; s.v[k] = 0; }
+    for (int b = 0; b < 32; ++b) {   // little-endian (ecdsa/native.rs:196-208)
+        r.v[b >> 2] |= (uint32_t)rec[73 + b] << (8 * (b & 3));
+        s.v[b >> 2] |= (uint32_t)rec[105 + b] << (8 * (b & 3));
+    }
+    const bool y_odd = rec[137] != 0;
+    uint8_t code = REC_OK;
+    if (f_is_zero(r) || f_is_zero(s) || f_geq(r, N.m) || f_geq(s, N.m)) code = REC_BAD_SCALAR;
+
+    // ---- R = (r, y): y = (r^3 + 7)^((p + 1) / 4) ------------------------------------------------------
+    F256 rx = f_to_mont(r, P);
+    F256 rhs = f_add(f_mul(f_mul(rx, rx, P), rx, P), K->seven, P);
+    F256 e;
+    {
+        // (p + 1) / 4: p + 1 does not carry out of 256 bits
+        uint64_t c = 1;
+        uint32_t p1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { uint64_t t = (uint64_t)P.m[k] + c; p1[k] = (uint32_t)t; c = t >> 32; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e.v[k] = (p1[k] >> 2) | (k < 7 ? p1[k + 1] << 30 : 0u);
+    }
+    F256 ry = f_pow(rhs, e, P);
+    if (code == REC_OK && !f_eq(f_mul(ry, ry, P), rhs)) code = REC_NOT_ON_CURVE;
+    if ((f_from_mont(ry, P).v[0] & 1u) != (y_odd ? 1u : 0u)) ry = f_sub(f_load_mod(P.m), ry, P);   // p - y (y != 0 on this curve)
+
+    // ---- Q = u1 * G + u2 * R,  u1 = -hash / r,  u2 = s / r  (mod n) -----------------------------------------
+    F256 ri = f_inv(f_to_mont(r, N), N);
+    F256 zero;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) zero.v[k] = 0;
+    F256 u1 = f_from_mont(f_sub(zero, f_mul(ri, f_to_mont(hash, N), N), N), N);
+    F256 u2 = f_from_mont(f_mul(ri, f_to_mont(s, N), N), N);
+    JPt acc;
+    acc.x = zero; acc.y = f_load_mod(P.one); acc.z = zero;
+    for (int bit = 255; bit >= 0; --bit) {
+        acc = j_double(acc, P);
+        if ((u1.v[bit >> 5] >> (bit & 31)) & 1) acc = j_add_affine(acc, K->gx, K->gy, P);
+        if ((u2.v[bit >> 5] >> (bit & 31)) & 1) acc = j_add_affine(acc, rx, ry, P);
+    }
+    if (code == REC_OK && f_is_zero(acc.z)) code = REC_INFINITY;
+    F256 zi = f_inv(acc.z, P), zi2 = f_mul(zi, zi, P);
+    F256 qx = f_from_mont(f_mul(acc.x, zi2, P), P), qy = f_from_mont(f_mul(acc.y, f_mul(zi2, zi, P), P), P);
+
+    // ---- address = Keccak-256(x || y big-endian)[12..32] ---------------------------------------------------
+    uint64_t ks[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) ks[k] = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {   // lane w of the sponge = bytes 8w..8w+7 of the message, little-endian words
+        // big-endian x: byte j of the message is byte (31 - j) of the integer
+        uint64_t lo = bswap32(qx.v[7 - 2 * w]), hi = bswap32(qx.v[6 - 2 * w]);
+        ks[w] = lo | (hi << 32);
+        lo = bswap32(qy.v[7 - 2 * w]); hi = bswap32(qy.v[6 - 2 * w]);
+        ks[4 + w] = lo | (hi << 32);
+    }
+    ks[8] ^= 0x01ULL;                    // Keccak padding after 64 message bytes
+    ks[16] ^= 0x8000000000000000ULL;     // last byte of the 136-byte rate
+    keccak_f1600(ks);
+    for (int b = 0; b < 20; ++b) {
+        const int pos = 12 + b;
+        out[b] = code == REC_OK ? (uint8_t)(ks[pos >> 3] >> (8 * (pos & 7))) : 0;
+    }
+    if (ko) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ko[k] = code == REC_OK ? qx.v[k] : 0u; ko[8 + k] = code == REC_OK ? qy.v[k] : 0u; }
+    }
+    *status_out = code;
+}
+
+__global__ __launch_bounds__(256) void k_recover(const uint8_t* __restrict__ recs, uint32_t n, const RecoverConsts* __restrict__ K,
+                                                 uint8_t* __restrict__ attesters, uint8_t* __restrict__ keys, uint8_t* __restrict__ status) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // record layout: about[20] domain[20] value message[32] sig_r[32] sig_s[32] rec_id
+    recover_lane(recs + (size_t)i * sizeof(et_attestation), K, attesters + (size_t)i * 20,
+                 keys ? reinterpret_cast<uint32_t*>(keys + (size_t)i * 64) : nullptr, status + i);
+}
+
+static void put(uint32_t* dst, const U256h& v) {
+    for (int i = 0; i < 4; ++i) { dst[2 * i] = (uint32_t)v.l[i]; dst[2 * i + 1] = (uint32_t)(v.l[i] >> 32); }
+}
+static void fill_mod(ModConst& mc, const U256h& m) {
+    Mont M(m);
+    std::memset(&mc, 0, sizeof mc);
+    put(mc.m, M.m);
+    put(mc.r2, M.r2);
+    put(mc.one, M.one);
+    mc.n0 = (uint32_t)M.n0;
+}
+
+
+// the three moduli, the generator, Poseidon's parameters, all in Montgomery form (R = 2^256)
+static int build_consts(RecoverConsts& K) {
+    U256h rmod;
+    std::memcpy(rmod.l, FR_MOD, 32);
+    fill_mod(K.mod[MOD_P], SECP_P);
+    fill_mod(K.mod[MOD_N], SECP_N);
+    fill_mod(K.mod[MOD_R], rmod);
+    Mont MP(SECP_P), MR(rmod);
+    put(K.gx.v, MP.to(SECP_GX));
+    put(K.gy.v, MP.to(SECP_GY));
+    put(K.seven.v, MP.to(U256h{{7, 0, 0, 0}}));
+    std::vector<FrRaw> rc, mds;
+    poseidon5_parameters(rc, mds);
+    if (rc.size() != 340 || mds.size() != 25) { set_error("internal: Poseidon parameter count"); return ET_E_UNSUPPORTED; }
+    for (size_t i = 0; i < 340; ++i) { U256h v; std::memcpy(v.l, rc[i].l, 32); put(K.rc[i].v, MR.to(v)); }
+    for (size_t i = 0; i < 25; ++i) { U256h v; std::memcpy(v.l, mds[i].l, 32); put(K.mds[i].v, MR.to(v)); }
+    return ET_OK;
+}
+
+}  // namespace et
+
+using namespace et;
+
+extern "C" int et_attestations_recover_gpu(const et_attestation* atts, size_t n, uint8_t* attesters, uint8_t* public_keys, int device) {
+    if ((!atts || !attesters) && n) return ET_E_INVALID_ARG;
+    if (n > 0xFFFFFFFFu) return ET_E_UNSUPPORTED;
+    int ndev = 0;
+    HIP_TRY_E(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { set_error("no HIP device"); return ET_E_NO_DEVICE; }
+    if (device < 0) HIP_TRY_E(hipGetDevice(&device));
+    HIP_TRY_E(hipSetDevice(device));
+    if (n == 0) return ET_OK;
+
+    std::vector<RecoverConsts> kc(1);
+    RecoverConsts& K = kc[0];
+    int rcc = build_consts(K);
+    if (rcc) return rcc;
+
+    uint8_t *d_recs = nullptr, *d_addr = nullptr, *d_keys = nullptr, *d_status = nullptr;
+    RecoverConsts* d_k = nullptr;
+    struct Free { uint8_t** a; uint8_t** b; uint8_t** c; uint8_t** d; RecoverConsts** k;
+                  ~Free() { if (*a) (void)hipFree(*a); if (*b) (void)hipFree(*b); if (*c) (void)hipFree(*c); if (*d) (void)hipFree(*d); if (*k) (void)hipFree(*k); } }
+        guard{&d_recs, &d_addr, &d_keys, &d_status, &d_k};
+    HIP_TRY_E(hipMalloc((void**)&d_recs, n * sizeof(et_attestation)));
+    HIP_TRY_E(hipMalloc((void**)&d_addr, n * 20));
+    if (public_keys) HIP_TRY_E(hipMalloc((void**)&d_keys, n * 64));
+    HIP_TRY_E(hipMalloc((void**)&d_status, n));
+    HIP_TRY_E(hipMalloc((void**)&d_k, sizeof(RecoverConsts)));
+    HIP_TRY_E(hipMemcpy(d_recs, atts, n * sizeof(et_attestation), hipMemcpyHostToDevice));
+    HIP_TRY_E(hipMemcpy(d_k, &K, sizeof(RecoverConsts), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_recover, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_recs, (uint32_t)n, d_k, d_addr, d_keys, d_status);
+    HIP_TRY_E(hipGetLastError());
+    std::vector<uint8_t> st(n);
+    HIP_TRY_E(hipMemcpy(st.data(), d_status, n, hipMemcpyDeviceToHost));
+    HIP_TRY_E(hipMemcpy(attesters, d_addr, n * 20, hipMemcpyDeviceToHost));
+    if (public_keys) HIP_TRY_E(hipMemcpy(public_keys, d_keys, n * 64, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) {
+        if (st[i] == REC_OK) continue;
+        const char* why = st[i] == REC_BAD_SCALAR ? "signature scalar out of range"
+                        : st[i] == REC_NOT_ON_CURVE ? "signature r is not the x coordinate of a curve point"
+                                                    : "recovered key is the point at infinity";
+        set_error("attestation " + std::to_string(i) + ": " + why);
+        return ET_E_BAD_SIGNATURE;
+    }
+    return ET_OK;
+}
+
+// The lane function of the kernel compiled for the host, on one record: lets the device arithmetic be
+// checked where no GPU is present.  A self-test hook, not a compute path.
+extern "C" int et_attestation_recover_lane_host(const et_attestation* att, uint8_t attester[20], uint8_t public_key[64]) {
+    if (!att || !attester || !public_key) return ET_E_INVALID_ARG;
+    std::vector<RecoverConsts> kc(1);
+    int rc = build_consts(kc[0]);
+    if (rc) return rc;
+    uint8_t status = 0;
+    uint32_t key[16];
+    recover_lane(reinterpret_cast<const uint8_t*>(att), &kc[0], attester, key, &status);
+    std::memcpy(public_key, key, 64);
+    if (status != REC_OK) { set_error("lane status " + std::to_string((int)status)); return ET_E_BAD_SIGNATURE; }
+    return ET_OK;
+}

@@ -199,13 +199,17 @@ def attestation_hash(att):
     return int.from_bytes(bytes(out.b), "little")
 
 
-def recover_attesters(attestations, with_keys=False):
-    """SignedAttestationEth::recover_public_key + address_from_ecdsa_key for every record."""
+def recover_attesters(attestations, with_keys=False, gpu=False):
+    """SignedAttestationEth::recover_public_key + address_from_ecdsa_key for every record, on host
+    threads or (`gpu=True`) one GPU lane per record."""
     n = len(attestations)
-    arr = _c_attestations(attestations)
+    arr = attestations if isinstance(attestations, C.Array) else _c_attestations(attestations)
     who = (C.c_uint8 * max(20, 20 * n))()
     keys = (C.c_uint8 * max(64, 64 * n))()
-    check(lib().et_attestations_recover(arr, n, who, keys))
+    if gpu:
+        check(lib().et_attestations_recover_gpu(arr, n, who, keys, -1))
+    else:
+        check(lib().et_attestations_recover(arr, n, who, keys))
     addrs = [bytes(who[20 * k:20 * k + 20]) for k in range(n)]
     if not with_keys:
         return addrs
@@ -218,6 +222,19 @@ def public_key_of_secret(secret):
     pk, ad = (C.c_uint8 * 64)(), (C.c_uint8 * 20)()
     check(lib().et_secp256k1_public_key(sk, pk, ad))
     return bytes(pk), bytes(ad)
+
+
+def sign_attestation(secret, about, value, nonce, domain=bytes(20), message=bytes(32)):
+    """A signed record as the reference's client produces it (attestation.rs:117-140 over
+    ecdsa/native.rs:264-296), with the caller's nonce."""
+    att = SignedAttestationRaw(bytes(_addr(about)), bytes(_addr(domain)), int(value), bytes(message), bytes(32), bytes(32), 0)
+    h = _fr(attestation_hash(att))
+    sk = (C.c_uint8 * 32).from_buffer_copy(int(secret).to_bytes(32, "little"))
+    k = (C.c_uint8 * 32).from_buffer_copy(int(nonce).to_bytes(32, "little"))
+    r, s, rec = (C.c_uint8 * 32)(), (C.c_uint8 * 32)(), C.c_uint8(0)
+    check(lib().et_secp256k1_sign(sk, C.byref(h), k, r, s, C.byref(rec)))
+    att.sig_r, att.sig_s, att.rec_id = bytes(r), bytes(s), int(rec.value)
+    return att
 
 
 def opinion_validate(public_key, attestations, set_addresses, domain=bytes(20)):

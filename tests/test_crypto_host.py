@@ -122,3 +122,19 @@ def test_opinion_validate_matches_restatement():
     with pytest.raises(pa.EigenTrustError) as e:                   # :75
         pa.opinion_validate(key, swapped, addrs, domain)
     assert e.value.code == _ffi.ET_E_BAD_ABOUT
+
+
+def test_device_lane_code_compiled_for_the_host_matches_host_recovery():
+    """The GPU kernel's lane function (ecdsa.hip) built for the CPU: same source, same answers."""
+    import ctypes as C
+    rng = random.Random(21)
+    recs = [pa.sign_attestation(rng.randrange(1, cref.SECP_N), bytes(rng.randrange(256) for _ in range(20)), rng.randrange(256),
+                                rng.randrange(1, cref.SECP_N), bytes([rng.randrange(256)]) * 20,
+                                bytes([0xff] * 32) if k % 3 == 0 else bytes(32)) for k in range(24)]
+    recs += pa.read_attestations_csv(open(os.path.join(ASSETS, "attestations.csv")).read())
+    want_addr, want_keys = pa.recover_attesters(recs, with_keys=True)
+    for rec, addr, key in zip(recs, want_addr, want_keys):
+        c = rec._to_c()
+        a, k = (C.c_uint8 * 20)(), (C.c_uint8 * 64)()
+        _ffi.check(pa.lib().et_attestation_recover_lane_host(C.byref(c), a, k))
+        assert bytes(a) == addr and bytes(k) == key
