@@ -49,7 +49,7 @@ def algorithmic_bytes(variant, nnz, rows):
     return nnz * 8 + rows * 100
 
 
-def bench_small_sets(args, world, rank, device):
+def bench_small_sets(args, world, rank, device, red):
     """4096 independent 256-slot sets (240-256 members each, ~5 % all-zero rows), 20 iterations, exact:
     every rank converges its own 4096 / world sets, one workgroup per set, no communication.
     Edge-iterations count the dense edges the reference iterates over: n_valid * (n_valid - 1) per set."""
@@ -87,9 +87,9 @@ def bench_small_sets(args, world, rank, device):
     elapsed = time.perf_counter() - t0
     edges = float(batch.edges)
     if world > 1:
-        t = torch.tensor([elapsed, 0.0], dtype=torch.float64, device=device)
-        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
-        e = torch.tensor([edges], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e = torch.tensor([edges], dtype=torch.float64, device=red)
         dist.all_reduce(e)
         elapsed, edges = float(t[0]), float(e[0])
     out, status = batch.result_fr(st)
@@ -152,17 +152,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    # rehearsal knobs (one-GPU box): ET_BENCH_DEVICE pins every rank to one card, ET_BENCH_BACKEND=gloo stages the
+    # exchange through host memory; the driver's multi-GPU runs use neither
+    if "ET_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["ET_BENCH_DEVICE"])
+    backend = os.environ.get("ET_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     wl = args.workload
     if wl == "auto":
         wl = "c3" if world == 1 else "c4"
+    # small reductions travel on the device with nccl, on the host in a gloo rehearsal
+    red = device if backend == "nccl" else torch.device("cpu")
     if wl == "c5":
-        return bench_small_sets(args, world, rank, device)
+        return bench_small_sets(args, world, rank, device, red)
     kind, n, target_edges, desc = WORKLOADS[wl]
 
     t0 = time.time()
@@ -211,7 +221,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=red)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         ev_ms, ev_pairs = sg.graph.event_times()
@@ -245,7 +255,7 @@ def main():
     if "f64" in results:
         res, s64 = sg.graph.stats_f64(NUM_ITER - 1, st)
         if world > 1:
-            t = torch.tensor([res, s64], dtype=torch.float64, device=device)
+            t = torch.tensor([res, s64], dtype=torch.float64, device=red)
             dist.all_reduce(t)
             res, s64 = float(t[0]), float(t[1])
         checks["f64_sum_rel_err"] = abs(s64 - INITIAL * float(info.n_valid)) / (INITIAL * float(info.n_valid))
