@@ -410,6 +410,19 @@ int et_et_setup(const et_attestation *atts, size_t n_att, const uint8_t domain[2
                 uint64_t initial_hi, et_score *out, size_t cap, size_t *n_participants,
                 uint8_t *public_inputs, size_t public_inputs_cap);
 
+/* calculate_scores for attestation lists of any size: the attesters are recovered on the GPU
+ * (et_attestations_recover_gpu), the participants are all attesters and all `about` addresses in
+ * ascending order (every one of them a member: no slot limit), one edge per record (a later record of
+ * the same pair replaces an earlier one) goes through et_graph_build, and converge runs on the GPU.
+ * Outputs (each may be NULL): addresses = participants * 20 bytes, scores_fr / scores_f64 in that
+ * order.  All NULL: only *n_participants is set.  No rational scores (no arbitrary precision at
+ * this size).  Errors: ET_E_BAD_DOMAIN, ET_E_BAD_SIGNATURE, ET_E_INSUFFICIENT_PEERS, and those of
+ * et_graph_build / et_graph_converge_*. */
+int et_scores_from_attestations(const et_attestation *atts, size_t n_att, const uint8_t domain[20],
+                                uint32_t num_iterations, uint64_t initial_lo, uint64_t initial_hi,
+                                uint8_t *addresses, et_fr *scores_fr, double *scores_f64, size_t cap,
+                                size_t *n_participants);
+
 /* Field arithmetic self-test hook: runs the device multiply-accumulate + reduction used by the
  * Fr kernel on `count` (a, b) pairs and returns a[i]*b[i] mod r (canonical in, canonical out). */
 int et_dev_fr_mul(uint32_t count, const et_fr *a, const et_fr *b, et_fr *out);

@@ -10,4 +10,4 @@ from .graph import Batch, Graph, Plan, R_MODULUS, fr_bytes_from_ints, fr_ints_fr
 from .scores import (ETPublicInputs, Score, SignedAttestationRaw, Threshold, attestation_hash, big_to_fe_rat,  # noqa: F401
                      calculate_scores, et_circuit_setup, keccak256, opinion_validate, pack_score, poseidon5_permute,
                      poseidon5_sponge, public_key_of_secret, read_attestations_csv, recover_attesters,
-                     scalar_from_address, sign_attestation, write_attestations_csv, write_scores_csv)
+                     scalar_from_address, scores_from_attestations, sign_attestation, write_attestations_csv, write_scores_csv)

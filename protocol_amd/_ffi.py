@@ -163,6 +163,7 @@ PROTOTYPES = {
     "et_secp256k1_sign": (i32, [vp, vp, vp, vp, vp, vp]),
     "et_opinion_validate": (i32, [vp, P(EtAttestation), vp, vp, u32, vp, vp, vp]),
     "et_et_setup": (i32, [P(EtAttestation), C.c_size_t, vp, u32, u32, u64, u64, P(EtScore), C.c_size_t, P(C.c_size_t), vp, C.c_size_t]),
+    "et_scores_from_attestations": (i32, [P(EtAttestation), C.c_size_t, vp, u32, u64, u64, vp, vp, vp, C.c_size_t, P(C.c_size_t)]),
     "et_local_scores": (i32, [P(EtAttestation), vp, C.c_size_t, vp, u32, u32, u64, u64, P(EtScore), C.c_size_t, P(C.c_size_t)]),
 }
 

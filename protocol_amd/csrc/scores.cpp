@@ -413,4 +413,62 @@ int et_local_scores(const et_attestation* atts, const uint8_t* attesters, size_t
     return ET_OK;
 }
 
+int et_scores_from_attestations(const et_attestation* atts, size_t n_att, const uint8_t domain[20], uint32_t num_iterations,
+                                uint64_t initial_lo, uint64_t initial_hi, uint8_t* addresses, et_fr* scores_fr, double* scores_f64,
+                                size_t cap, size_t* n_participants) {
+    if ((!atts && n_att) || !domain || !n_participants) return ET_E_INVALID_ARG;
+    typedef std::array<uint8_t, 20> Addr;
+    for (size_t k = 0; k < n_att; ++k)
+        if (std::memcmp(atts[k].domain, domain, 20) != 0) {   // opinion/native.rs:76
+            set_error("attestation " + std::to_string(k) + " belongs to another domain");
+            return ET_E_BAD_DOMAIN;
+        }
+    // attesters, one GPU lane per record (lib.rs:351-358)
+    std::vector<uint8_t> who(20 * std::max<size_t>(1, n_att));
+    int rc = et_attestations_recover_gpu(atts, n_att, who.data(), nullptr, -1);
+    if (rc) return rc;
+    // participants in ascending address order (the BTreeSet of lib.rs:344-361)
+    std::vector<Addr> parts(2 * n_att);
+    for (size_t k = 0; k < n_att; ++k) {
+        std::memcpy(parts[2 * k].data(), atts[k].about, 20);
+        std::memcpy(parts[2 * k + 1].data(), who.data() + 20 * k, 20);
+    }
+    std::sort(parts.begin(), parts.end());
+    parts.erase(std::unique(parts.begin(), parts.end()), parts.end());
+    *n_participants = parts.size();
+    if (parts.size() < 2) { set_error("Number of participants is less than the minimum number of neighbours"); return ET_E_INSUFFICIENT_PEERS; }
+    if (parts.size() > 0xFFFFFFF0u) return ET_E_UNSUPPORTED;
+    if (!addresses && !scores_fr && !scores_f64) return ET_OK;
+    if (cap < parts.size()) return ET_E_BUFFER_TOO_SMALL;
+    auto index_of = [&](const uint8_t* a) -> uint32_t {
+        Addr key;
+        std::memcpy(key.data(), a, 20);
+        return (uint32_t)(std::lower_bound(parts.begin(), parts.end(), key) - parts.begin());
+    };
+    // one edge per record, in record order: a later record of the same (attester, about) pair replaces an
+    // earlier one (lib.rs:404-419); self-attestations and zero values drop out in the filter (native.rs:248-260)
+    std::vector<uint32_t> from(n_att), to(n_att), val(n_att);
+    for (size_t k = 0; k < n_att; ++k) {
+        from[k] = index_of(who.data() + 20 * k);
+        to[k] = index_of(atts[k].about);
+        val[k] = atts[k].value;
+    }
+    et_build_opts opts;
+    std::memset(&opts, 0, sizeof opts);
+    opts.n_seg = 1;
+    opts.variants = (scores_fr ? ET_VARIANT_FR : 0) | (scores_f64 ? ET_VARIANT_F64 : 0);
+    opts.device = -1;
+    if (!opts.variants) opts.variants = ET_VARIANT_FR;
+    et_graph* g = nullptr;
+    if ((rc = et_graph_build((uint32_t)parts.size(), nullptr, n_att, from.data(), to.data(), val.data(), nullptr, &opts, &g))) return rc;
+    struct Guard { et_graph* g; ~Guard() { et_graph_free(g); } } guard{g};
+    if (scores_fr && (rc = et_graph_converge_fr(g, num_iterations, initial_lo, initial_hi, scores_fr))) return rc;
+    if (scores_f64) {
+        const double init = (double)initial_lo + 18446744073709551616.0 * (double)initial_hi;
+        if ((rc = et_graph_converge_f64(g, num_iterations, init, 0.0, nullptr, scores_f64, nullptr))) return rc;
+    }
+    if (addresses) for (size_t i = 0; i < parts.size(); ++i) std::memcpy(addresses + 20 * i, parts[i].data(), 20);
+    return ET_OK;
+}
+
 }  // extern "C"

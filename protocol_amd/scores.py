@@ -294,6 +294,25 @@ def calculate_scores(attestations, attesters=None, domain=bytes(20), num_neighbo
     return [Score._from_c(c) for c in out[:count.value]]
 
 
+def scores_from_attestations(attestations, domain=bytes(20), num_iterations=20, initial_score=1000, f64=False):
+    """calculate_scores for attestation lists of any size, all on the GPU except the address bookkeeping:
+    returns (addresses ascending, field scores as integers[, f64 scores])."""
+    n = len(attestations)
+    arr = attestations if isinstance(attestations, C.Array) else _c_attestations(attestations)
+    count = C.c_size_t(0)
+    dom = _addr(domain)
+    head = (arr, n, dom, num_iterations, initial_score & (2**64 - 1), initial_score >> 64)
+    check(lib().et_scores_from_attestations(*head, None, None, None, 0, C.byref(count)))
+    m = count.value
+    addrs = (C.c_uint8 * (20 * m))()
+    fr = np.zeros((m, 32), dtype=np.uint8)
+    d64 = np.zeros(m, dtype=np.float64) if f64 else None
+    check(lib().et_scores_from_attestations(*head, addrs, fr.ctypes.data, d64.ctypes.data if f64 else None, m, C.byref(count)))
+    out_addr = [bytes(addrs[20 * i:20 * i + 20]) for i in range(m)]
+    ints = [int.from_bytes(fr[i].tobytes(), "little") for i in range(m)]
+    return (out_addr, ints, d64) if f64 else (out_addr, ints)
+
+
 class ETPublicInputs:
     """circuit.rs:84-151."""
 

@@ -132,3 +132,41 @@ def test_signed_attestation_lists_match_the_restatement(nn, iters, seed):
         assert int.from_bytes(g.score_fr, "big") == fr and g.rational == q
     assert pub.scores == want_fr and pub.participants == [int.from_bytes(p, "big") for p in parts] + [0] * (nn - len(parts))
     assert pa.calculate_scores(atts, who, num_neighbours=nn, num_iterations=iters) == got
+
+
+def test_scores_from_attestations_any_size():
+    """The large-set path: attesters recovered on the GPU, graph engine for the iteration."""
+    atts = pa.read_attestations_csv(open(os.path.join(ASSETS, "attestations.csv")).read())
+    addrs, scores = pa.scores_from_attestations(atts)
+    assert [a.hex() for a in addrs] == ["70997970c51812dc3a010c7d01b50e0d17dc79c8", ANVIL_0[2:]] and scores == [1000, 1000]
+
+    rng = random.Random(77)
+    n_peers = 180
+    secrets = [rng.randrange(1, cref.SECP_N) for _ in range(n_peers)]
+    keys = [pa.public_key_of_secret(s)[1] for s in secrets]
+    silent = [bytes(rng.randrange(256) for _ in range(20)) for _ in range(15)]      # rated, never attesting: dangling
+    atts, who = [], []
+    for _ in range(2500):
+        i = rng.randrange(n_peers)
+        about = rng.choice(keys + silent)
+        atts.append(pa.sign_attestation(secrets[i], about, rng.randrange(0, 256), rng.randrange(1, cref.SECP_N)))
+        who.append(keys[i])
+    allp = sorted({a.about for a in atts} | set(who))
+    s = ref.EigenTrustSet(len(allp), 20, 1000, 0)
+    for p in allp:
+        s.add_member(int.from_bytes(p, "big"))
+    matrix = {p: [0] * len(allp) for p in set(who)}
+    pos = {p: i for i, p in enumerate(allp)}
+    for a, w in zip(atts, who):
+        matrix[w][pos[a.about]] = a.value
+    for p in allp:
+        if p in matrix:
+            s.update_op(int.from_bytes(p, "big"), matrix[p])
+    want = s.converge()
+    addrs, scores, d64 = pa.scores_from_attestations(atts, f64=True)
+    assert addrs == allp and scores == want
+    # the f64 variant tracks the same scores (loosely: the field scores are not comparable digit by digit)
+    assert abs(float(d64.sum()) - 1000.0 * len(allp)) <= 1e-6 * 1000.0 * len(allp)
+    with pytest.raises(pa.EigenTrustError) as e:
+        pa.scores_from_attestations(atts, domain=bytes([1]) * 20)
+    assert e.value.code == _ffi.ET_E_BAD_DOMAIN
