@@ -79,10 +79,11 @@ static void read_opts(const et_build_opts* opts, BuildOpts& bo, int& variants, i
     device = opts->device;
 }
 
-// Tuning knobs for experiments (not part of the ABI): ET_TARGET_WORK, ET_LONG_ROW, ET_F64_BLOCKS.
+// Tuning knobs for experiments (not part of the ABI): ET_TARGET_WORK, ET_LONG_ROW, ET_F64_BLOCKS, ET_HOT_PREFIX.
 static void read_env(BuildOpts& bo) {
     if (const char* e = getenv("ET_TARGET_WORK")) bo.target_work = (uint32_t)atoi(e);
     if (const char* e = getenv("ET_LONG_ROW")) bo.long_row = (uint32_t)atoi(e);
+    if (const char* e = getenv("ET_HOT_PREFIX")) bo.hot_f64 = (uint32_t)atoi(e);
     if (const char* e = getenv("ET_F64_BLOCKS")) bo.f64_blocks = (uint32_t)atoi(e);
 }
 

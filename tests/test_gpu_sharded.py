@@ -30,9 +30,13 @@ def _worker(rank, world, port, case, ret):
     sg = ShardedGraph(n, frm, to, value_u32=val, member=member, device=torch.device("cuda", 0))
     fr = sg.converge_fr(iters, 1000)          # raises on a conservation failure
     f64 = sg.converge_f64(iters, 1000.0)
+    damped = sg.converge_f64(iters, 1000.0, alpha=0.15)     # default pre-trust: the initial scores
+    start = sg.converge_fr(0, 1000)                         # zero iterations: the initial vector
     if rank == 0:
         ret["fr"] = fr.tobytes()
         ret["f64"] = f64.tolist()
+        ret["damped"] = damped.tolist()
+        ret["start"] = start.tobytes()
         ret["nnz"] = sg.nnz
     dist.barrier()
     dist.destroy_process_group()
@@ -60,3 +64,9 @@ def test_sharded_converge_matches_oracle(world):
     assert ret["fr"] == exp.tobytes()
     got = np.array(ret["f64"], dtype=np.longdouble)
     assert float(np.abs(got - eld).sum() / np.abs(eld).sum()) <= 1e-9
+    rc, _e, dld, _r, _n, _s = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000.0,
+                                                           alpha=0.15, pretrust=1000.0 * member, want_ld=True)
+    assert rc == 0
+    got = np.array(ret["damped"], dtype=np.longdouble)
+    assert float(np.abs(got - dld).sum() / np.abs(dld).sum()) <= 1e-9
+    assert ret["start"] == pa.fr_bytes_from_ints([1000 if m else 0 for m in member]).tobytes()
