@@ -206,12 +206,13 @@ __global__ __launch_bounds__(1024) void k_batch_fr_u8(BatchArgsU8 au) {
     const BatchArgs& a = au.b;
     extern __shared__ uint4 lds4[];
     const uint32_t n = a.n, cols = au.cols, parts = au.parts;
-    // LDS carve-up: s[n], next s[n], xs[n] (2 x uint4 each), 16 reduction slots, partial
-    // accumulators [10][parts - 1][n], optional opinion matrix
+    // LDS carve-up: s[n], next s[n] (2 x uint4 each), xs[n] as sixteen 16-bit limbs, one per dword
+    // (4 x uint4 each), 16 reduction slots, partial accumulators [10][parts - 1][n], optional
+    // opinion matrix
     uint4* s_l = lds4;
     uint4* sn_l = lds4 + 2 * (size_t)n;
     uint4* xs_l = lds4 + 4 * (size_t)n;
-    uint4* red_l = lds4 + 6 * (size_t)n;
+    uint4* red_l = lds4 + 8 * (size_t)n;
     uint32_t* part_l = reinterpret_cast<uint32_t*>(red_l + 2 * 16 + 2);
     uint8_t* v_l = reinterpret_cast<uint8_t*>(part_l + (size_t)10 * (parts - 1) * n);
     __shared__ uint32_t sh_D[8];
@@ -262,7 +263,10 @@ __global__ __launch_bounds__(1024) void k_batch_fr_u8(BatchArgsU8 au) {
             U256 f = u256_load(a.scale + 2 * ((size_t)set * n + k));
             Acc t = acc_zero();
             acc_mac(t, sk, f);
-            u256_store(xs_l + 2 * k, acc_redc288(t));
+            const U256 xk = acc_redc288(t);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                xs_l[4 * k + q] = make_uint4(xk.v[2 * q] & 0xFFFFu, xk.v[2 * q] >> 16, xk.v[2 * q + 1] & 0xFFFFu, xk.v[2 * q + 1] >> 16);
             if (dng[k]) dpart = fr_add(dpart, sk);
         }
         if ((uint32_t)wave * 64 < n) {                        // the other wavefronts hold no element of s
@@ -298,13 +302,14 @@ __global__ __launch_bounds__(1024) void k_batch_fr_u8(BatchArgsU8 au) {
             uint32_t idx = j0 * n + ii;                       // n <= 1024: fits 32 bits
             for (uint32_t j = j0; j < j1; ++j, idx += n) {
                 const uint32_t op = vsrc[idx];
-                const uint4 x0 = xs_l[2 * j], x1 = xs_l[2 * j + 1];
-                const uint32_t xw[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                // the same address in every lane: LDS broadcast; limb (16 bit) x opinion (8 bit) < 2^24
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const uint32_t u = __builtin_amdgcn_readfirstlane(xw[q]);
-                    cs[2 * q] += __umul24(u & 0xFFFFu, op);
-                    cs[2 * q + 1] += __umul24(u >> 16, op);
+                for (int q = 0; q < 4; ++q) {
+                    const uint4 x = xs_l[4 * j + q];
+                    cs[4 * q] += __umul24(x.x, op);
+                    cs[4 * q + 1] += __umul24(x.y, op);
+                    cs[4 * q + 2] += __umul24(x.z, op);
+                    cs[4 * q + 3] += __umul24(x.w, op);
                 }
             }
             acc10_fold(acc, cs);
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(1024) void k_batch_fr_u8(BatchArgsU8 au) {
 }
 
 static size_t batch_u8_lds_bytes(uint32_t n, uint32_t parts, bool vals_in_lds) {
-    size_t b = (6 * (size_t)n + 2 * 16 + 2) * sizeof(uint4) + (size_t)40 * (parts - 1) * n;
+    size_t b = (8 * (size_t)n + 2 * 16 + 2) * sizeof(uint4) + (size_t)40 * (parts - 1) * n;
     if (vals_in_lds) b += (size_t)n * n;
     return b;
 }
