@@ -142,9 +142,9 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     }
     g.nnz = nnz;
     // ---- 5. global row order ------------------------------------------------------------------
-    // Active peers: the opt.hot_fr most-gathered (highest out-degree), then the next most-gathered up
-    // to opt.hot_f64, then the rest; inside each group by in-degree (descending) so that the 64 rows
-    // of a slice have similar lengths.  Dangling peers follow.
+    // Active peers: the opt.hot_prefix most-gathered (highest out-degree), then the rest; inside each
+    // group by in-degree (descending) so that the 64 rows of a slice have similar lengths.  Dangling
+    // peers follow.
     const uint32_t n_active = n_valid - n_dangling;
     std::vector<uint32_t> order;
     order.reserve(n_valid);
@@ -160,13 +160,10 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         return a < b;
     };
     {
-        const uint32_t h1 = std::min<uint32_t>(n_active, std::max(opt.hot_f64, opt.hot_fr));
-        const uint32_t h0 = std::min<uint32_t>(h1, std::min(opt.hot_f64, opt.hot_fr));
+        const uint32_t h1 = std::min<uint32_t>(n_active, opt.hot_prefix);
         auto b = order.begin();
         if (h1 < n_active) std::nth_element(b, b + h1, b + n_active, by_out);
-        if (h0 < h1) std::nth_element(b, b + h0, b + h1, by_out);
-        std::sort(b, b + h0, by_deg);
-        std::sort(b + h0, b + h1, by_deg);
+        std::sort(b, b + h1, by_deg);
         std::sort(b + h1, b + n_active, by_deg);
     }
     std::sort(order.begin() + n_active, order.end(), by_deg);
@@ -187,8 +184,6 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         uint64_t share = ((uint64_t)target_work * n_dangling + n_valid - 1) / n_valid;
         geo.nd_cap = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(16, (share + 15) / 16 * 16));
     }
-    geo.hot_f64 = std::min<uint32_t>(geo.rows_cap, (opt.hot_f64 / G) / 64 * 64);
-    geo.hot_fr = std::min<uint32_t>(geo.rows_cap, (opt.hot_fr / G) / 64 * 64);
     {
         // f64 workgroups: one per CU unless the rows of a workgroup would not fit its LDS accumulators
         // (12288 rows plus the slack below stay under 160 KiB of f64 accumulators)

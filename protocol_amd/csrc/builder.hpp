@@ -35,9 +35,8 @@ struct BuildOpts {
     uint32_t seg = 0;            // this GPU
     uint32_t long_row = 128;     // in-degree above which a row is spread over a whole wavefront
     uint32_t target_work = 16384; // wavefront work items per iteration launch (several rounds of 256 CUs x 16 waves)
-    uint32_t hot_f64 = 16384;    // the most-attesting (most gathered) peers take the first positions: one contiguous, cache-resident prefix
+    uint32_t hot_prefix = 16384; // the most-attesting (most gathered) peers take the first positions: one contiguous prefix of the vector
     uint32_t f64_blocks = 256;   // workgroups of the f64 variant (one per CU)
-    uint32_t hot_fr = 0;         // optional second, smaller prefix level (0 = off)
 };
 
 struct HostGraph {

@@ -83,7 +83,7 @@ static void read_opts(const et_build_opts* opts, BuildOpts& bo, int& variants, i
 static void read_env(BuildOpts& bo) {
     if (const char* e = getenv("ET_TARGET_WORK")) bo.target_work = (uint32_t)atoi(e);
     if (const char* e = getenv("ET_LONG_ROW")) bo.long_row = (uint32_t)atoi(e);
-    if (const char* e = getenv("ET_HOT_PREFIX")) bo.hot_f64 = (uint32_t)atoi(e);
+    if (const char* e = getenv("ET_HOT_PREFIX")) bo.hot_prefix = (uint32_t)atoi(e);
     if (const char* e = getenv("ET_F64_BLOCKS")) bo.f64_blocks = (uint32_t)atoi(e);
 }
 

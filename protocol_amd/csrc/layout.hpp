@@ -5,13 +5,16 @@
 // in-edges, because the iteration new_s[i] = sum_j c_ji * s[j] (native.rs:319-329) is then a
 // row-wise dot product with no write conflicts.
 //
-// Rows are grouped in slices of 64 (one wavefront lane per row).  A slice stores its edges
-// step-major: entry (step k, lane l) lives at (off + k) * 64 + l, so every load of the edge
+// Two arrangements of the same edges are kept.
+// Exact variant: rows are grouped in slices of 64 (one wavefront lane per row).  A slice stores its
+// edges step-major: entry (step k, lane l) lives at (off + k) * 64 + l, so every load of the edge
 // stream is one contiguous 64-lane access.  A row with many in-edges gets a slice of its own whose
 // 64 lanes each hold every 64th edge of that one row and are summed across the wavefront.
+// f64 variant: one edge list per workgroup, sorted by source, for rows whose accumulators the
+// workgroup keeps in LDS ("blocked sweep", see engine.hip).
 //
-// The peers gathered most often (highest out-degree) are placed first, so that a prefix of every
-// segment can be staged in LDS.
+// The peers gathered most often (highest out-degree) are placed first: the busiest part of the
+// trust vector is one contiguous prefix.
 //
 // Trust vectors live in "position" order: G segments (one per GPU that owns rows; G = 1 on a single
 // GPU), each `rows_cap` row entries followed by `nd_cap` entries holding that GPU's partial sums of
@@ -44,7 +47,6 @@ struct WorkDesc {
 };
 static const uint32_t WORK_DANGLING = 1u;
 
-// A source index in the edge stream: segment in the top 3 bits, local row below.
 // Rows are handed to the workgroups of a blocked sweep in groups of BLOCK_GROUP consecutive rows (position
 // order is degree order, so the heaviest rows sit together: small groups keep the heaviest group well
 // below a workgroup's share of the edges).
@@ -56,6 +58,7 @@ inline uint32_t dangling_blocks(uint32_t blocks, uint32_t groups_per_block, uint
     uint32_t d = need > 256 ? need : 256;
     return d < blocks ? d : blocks;
 }
+// A source index in an edge record: segment in the top 3 bits, local row below.
 static const uint32_t COL_SEG_SHIFT = 29;
 static const uint32_t COL_LOCAL_MASK = (1u << COL_SEG_SHIFT) - 1;
 
@@ -69,9 +72,6 @@ struct Geometry {
     uint32_t n_active_pad; // rounded up to 64 * G
     uint32_t n_dangling;   // member peers whose filtered row is empty
     uint32_t n_dangling_pad;
-    // The first hot_* local rows of every segment hold the most frequently gathered sources; the
-    // step kernels keep them in LDS (per variant, because the entry size differs).
-    uint32_t hot_f64, hot_fr;
     // f64 blocked sweep: the segment's BLOCK_GROUP-row groups are handed to f64_blocks workgroups, each
     // of which keeps up to f64_rb row accumulators in LDS and walks its edges in ascending source order.
     uint32_t f64_blocks, f64_rb;
