@@ -7,7 +7,8 @@
 // and the reductions the next launch / the caller need: the score mass D' of dangling peers, the
 // sum of scores (conservation check, native.rs:331-334), and the residual (f64: L1 distance,
 // Fr: number of changed rows).  Reductions are per-workgroup partial results combined in a fixed
-// order, so every run and every GPU count produces identical bits.
+// order.  The exact variant produces identical bits on every run and every GPU count; the f64
+// variant accumulates a row with LDS atomics whose order is not fixed, so its last bits may vary.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
