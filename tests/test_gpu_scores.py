@@ -170,3 +170,15 @@ def test_scores_from_attestations_any_size():
     with pytest.raises(pa.EigenTrustError) as e:
         pa.scores_from_attestations(atts, domain=bytes([1]) * 20)
     assert e.value.code == _ffi.ET_E_BAD_DOMAIN
+
+
+def test_cli_local_scores_regenerates_the_reference_asset(tmp_path):
+    import shutil
+    from protocol_amd import cli
+    shutil.copy(os.path.join(ASSETS, "attestations.csv"), tmp_path / "attestations.csv")
+    assert cli.main(["local-scores", "--assets", str(tmp_path)]) == 0
+    assert (tmp_path / "scores.csv").read_text() == open(os.path.join(ASSETS, "scores.csv")).read()
+    assert cli.main(["threshold", "--assets", str(tmp_path), "--peer", ANVIL_0, "--threshold", "999"]) == 0
+    assert cli.main(["threshold", "--assets", str(tmp_path), "--peer", ANVIL_0, "--threshold", "1001"]) == 1
+    assert cli.main(["local-scores", "--assets", str(tmp_path), "--large"]) == 0
+    assert (tmp_path / "scores.csv").read_text().splitlines()[1].endswith("03e8")
