@@ -162,7 +162,7 @@ int et_graph_info_get(const et_graph *g, et_graph_info *info);
  * Lets a caller (or a test) inspect how an attestation list was filtered, ordered, sliced and
  * split over segments.  Arrays stay owned by the plan. */
 typedef struct et_plan et_plan;
-typedef struct { uint32_t off, len, row0, nrows; } et_slice_desc;   /* nrows bit 31: wavefront-reduced row */
+typedef struct { uint32_t off, len, row0, nrows; } et_slice_desc;   /* nrows bits 0-7: rows, bits 8-11: log2(lanes per row) */
 typedef struct { uint32_t slice_begin, slice_end, flags, dslot; } et_work_desc;  /* one wavefront; flags bit 0: dangling rows */
 typedef struct {
     const uint32_t *pos_of_slot;      /* n: position of each slot's peer, 0xFFFFFFFF for empty slots  */

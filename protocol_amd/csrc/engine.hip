@@ -360,16 +360,14 @@ __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr(StepArgsFr a) {
     const int wave = threadIdx.x >> 6;
     const uint32_t stride = a.geo.seg_stride();
     const size_t my_base = (size_t)a.geo.seg * stride;
+    // The first wavefront prepares the dangling mass while the others already walk their first slice;
+    // the workgroup meets once, before the first row is finished (wavefronts without a work item have
+    // left by then and do not count at the barrier).
     if (wave == 0) fr_dangling_mass(a.x, a.geo, a.inv_nm1_w, lane, sh_d, sh_pd);
-    __syncthreads();
     const uint32_t gw = blockIdx.x * WPB_FR + wave;
     if (gw >= a.n_work) return;
     const WorkDesc wd = a.work[gw];
     const bool dang = (wd.flags & WORK_DANGLING) != 0;
-    Acc PD;
-#pragma unroll
-    for (int i = 0; i < 17; ++i) PD.v[i] = sh_pd[i];
-
     U256 tot = u256_zero(), dacc = u256_zero();
     uint32_t changed = 0;
     for (uint32_t s = wd.slice_begin; s < wd.slice_end; ++s) {
@@ -385,10 +383,14 @@ __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr(StepArgsFr a) {
             U256 xv = u256_load(a.x + 2 * ((size_t)(c >> COL_SEG_SHIFT) * stride + (c & COL_LOCAL_MASK)));
             acc_mac(acc, w, xv);
         }
-        const bool reduce = (sd.nrows & SLICE_REDUCE) != 0;
-        if (reduce) acc_wave_sum(acc);
-        const uint32_t row = reduce ? sd.row0 : sd.row0 + lane;
-        const bool live = reduce ? lane == 0 : (uint32_t)lane < (sd.nrows & 0xFFu);
+        const uint32_t sh = slice_log2_lanes(sd.nrows);
+        acc_group_sum(acc, 1u << sh);
+        if (s == wd.slice_begin) __syncthreads();
+        Acc PD;
+#pragma unroll
+        for (int i = 0; i < 17; ++i) PD.v[i] = sh_pd[i];
+        const uint32_t row = sd.row0 + ((uint32_t)lane >> sh);
+        const bool live = ((uint32_t)lane & ((1u << sh) - 1)) == 0 && ((uint32_t)lane >> sh) < slice_rows(sd.nrows);
         if (live) {
             U256 old = u256_load(a.x + 2 * (my_base + row));
             if (dang) fr_add_dangling_term(acc, sh_d, old, a.inv_nm1_w);
@@ -421,8 +423,10 @@ __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr_raw(StepArgsFr a) {
     const int wave = threadIdx.x >> 6;
     const uint32_t stride = a.geo.seg_stride();
     const size_t my_base = (size_t)a.geo.seg * stride;
+    // The first wavefront prepares the dangling mass while the others already walk their first slice;
+    // the workgroup meets once, before the first row is finished (wavefronts without a work item have
+    // left by then and do not count at the barrier).
     if (wave == 0) fr_dangling_mass(a.x, a.geo, a.inv_nm1_w, lane, sh_d, sh_pd);
-    __syncthreads();
     const uint32_t gw = blockIdx.x * WPB_FR + wave;
     if (gw >= a.n_work) return;
     const WorkDesc wd = a.work[gw];
@@ -456,11 +460,12 @@ __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr_raw(StepArgsFr a) {
                 for (int i = 0; i < U; ++i) acc10_mac_u32(acc, xv[i], v[i]);
             }
         }
+        const uint32_t sh = slice_log2_lanes(sd.nrows);
+        acc10_group_sum(acc, 1u << sh);
+        if (s == wd.slice_begin) __syncthreads();
         Acc full = acc_from_acc10(acc);
-        const bool reduce = (sd.nrows & SLICE_REDUCE) != 0;
-        if (reduce) acc_wave_sum(full);
-        const uint32_t row = reduce ? sd.row0 : sd.row0 + lane;
-        const bool live = reduce ? lane == 0 : (uint32_t)lane < (sd.nrows & 0xFFu);
+        const uint32_t row = sd.row0 + ((uint32_t)lane >> sh);
+        const bool live = ((uint32_t)lane & ((1u << sh) - 1)) == 0 && ((uint32_t)lane >> sh) < slice_rows(sd.nrows);
         if (live) {
             U256 old = u256_load(a.own + 2 * (size_t)row);
             if (dang) {

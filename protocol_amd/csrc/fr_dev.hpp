@@ -267,4 +267,26 @@ ET_DEV void acc_wave_sum(Acc& a) {
     }
 }
 
+// Integer sum of the accumulators of `lanes` adjacent lanes (a power of two, the group is aligned);
+// every lane of the group receives the total.
+ET_DEV void acc_group_sum(Acc& a, uint32_t lanes) {
+    for (uint32_t off = lanes >> 1; off >= 1; off >>= 1) {
+        Acc o;
+#pragma unroll
+        for (int i = 0; i < 17; ++i) o.v[i] = __shfl_xor(a.v[i], (int)off, 64);
+        acc_add(a, o);
+    }
+}
+ET_DEV void acc10_group_sum(Acc10& a, uint32_t lanes) {
+    for (uint32_t off = lanes >> 1; off >= 1; off >>= 1) {
+        uint64_t cy = 0;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            uint64_t t = (uint64_t)a.v[i] + (uint32_t)__shfl_xor(a.v[i], (int)off, 64) + cy;
+            a.v[i] = (uint32_t)t;
+            cy = t >> 32;
+        }
+    }
+}
+
 }  // namespace et

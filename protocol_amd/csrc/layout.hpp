@@ -6,10 +6,11 @@
 // row-wise dot product with no write conflicts.
 //
 // Two arrangements of the same edges are kept.
-// Exact variant: rows are grouped in slices of 64 (one wavefront lane per row).  A slice stores its
-// edges step-major: entry (step k, lane l) lives at (off + k) * 64 + l, so every load of the edge
-// stream is one contiguous 64-lane access.  A row with many in-edges gets a slice of its own whose
-// 64 lanes each hold every 64th edge of that one row and are summed across the wavefront.
+// Exact variant: rows are grouped in slices, one wavefront each, 2^s lanes per row (s = 0 for large
+// graphs: 64 rows per slice).  A slice stores its edges step-major: entry (step k, lane l) lives at
+// (off + k) * 64 + l, so every load of the edge stream is one contiguous 64-lane access.  A row with
+// many in-edges gets a slice of its own (s = 6) whose 64 lanes each hold every 64th edge of that
+// one row and are summed across the wavefront.
 // f64 variant: one edge list per workgroup, sorted by source, for rows whose accumulators the
 // workgroup keeps in LDS ("blocked sweep", see engine.hip).
 //
@@ -35,9 +36,14 @@ struct SliceDesc {
     uint32_t off;    // first step of the slice in the edge stream (units of 64 entries)
     uint32_t len;    // number of steps
     uint32_t row0;   // local row of lane 0
-    uint32_t nrows;  // bit 31: all lanes belong to row0 (wavefront-reduced row); low bits: rows (1..64)
+    uint32_t nrows;  // bits 0..7: rows in the slice (1..64 >> s); bits 8..11: s = log2(lanes per row)
 };
-static const uint32_t SLICE_REDUCE = 0x80000000u;
+// A row of a slice is spread over 2^s adjacent lanes (lane l serves row l >> s and takes every 2^s-th
+// edge of it, starting with edge l & (2^s - 1)); the lanes' sums are added across the group.  s = 0 is
+// one lane per row, s = 6 one wavefront per row (rows with very many in-edges).  Small graphs use
+// s > 0 for all rows so that there are enough wavefronts to fill the GPU.
+ET_HD inline uint32_t slice_rows(uint32_t nrows) { return nrows & 0xFFu; }
+ET_HD inline uint32_t slice_log2_lanes(uint32_t nrows) { return (nrows >> 8) & 0xFu; }
 
 // Work of ONE wavefront: a contiguous run of slices of one class (active or dangling rows).
 struct WorkDesc {

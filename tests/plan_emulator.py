@@ -7,7 +7,6 @@ kernels walk, so CPU tests can check the builder's layout and the multi-GPU exch
 import numpy as np
 
 R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
-SLICE_REDUCE = 0x80000000
 INV_2_288 = pow(pow(2, 288, R), R - 2, R)
 INV_2_576 = pow(pow(2, 576, R), R - 2, R)
 
@@ -54,8 +53,8 @@ class SegmentEmulator:
             dacc = 0
             for s in range(sb, se):
                 off, ln, row0, nrows = p.slices[s]
-                reduce_ = bool(nrows & SLICE_REDUCE)
-                lanes = 64 if reduce_ else (nrows & 0xFF)
+                sh = (nrows >> 8) & 0xF            # log2(lanes per row)
+                n_rows = nrows & 0xFF
                 accs = [0] * 64
                 for k in range(ln):
                     for lane in range(64):
@@ -71,8 +70,9 @@ class SegmentEmulator:
                             v = float(p.value_u32[e]) if p.value_u32 is not None else float(p.value_fr[e])
                             if v:
                                 accs[lane] += v * p.scale_f64[c] * x[c]
-                rows = [(row0, sum(accs) % R if field else float(sum(accs)))] if reduce_ else \
-                    [(row0 + l, accs[l]) for l in range(lanes)]
+                group = 1 << sh
+                rows = [(row0 + r, (sum(accs[r * group:(r + 1) * group]) % R) if field else float(sum(accs[r * group:(r + 1) * group])))
+                        for r in range(n_rows)]
                 for row, acc in rows:
                     old = x[self.base + row]
                     if field:
