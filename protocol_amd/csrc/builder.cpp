@@ -188,8 +188,11 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         // f64 workgroups: one per CU unless the rows of a workgroup would not fit its LDS accumulators
         // (12288 rows plus the slack below stay under 160 KiB of f64 accumulators)
         const uint32_t n_groups = geo.rows_cap / BLOCK_GROUP, rb_max = 12288;
-        uint32_t B = std::max<uint32_t>(1, std::min<uint32_t>(opt.f64_blocks ? opt.f64_blocks : 256, n_groups));
-        B = std::max<uint32_t>(B, (geo.rows_cap + rb_max - 1) / rb_max);
+        const uint32_t per_round = opt.f64_blocks ? opt.f64_blocks : 256;
+        uint32_t B = std::max<uint32_t>(1, std::min<uint32_t>(per_round, n_groups));
+        const uint32_t need = (geo.rows_cap + rb_max - 1) / rb_max;
+        // more than one workgroup per CU: whole rounds, so that the last round is as full as the first
+        if (need > B) B = (need + per_round - 1) / per_round * per_round;
         geo.f64_blocks = B;
         // a quarter more accumulator slots than an even deal needs: workgroups holding light rows
         // take more 64-row groups than those holding heavy ones
