@@ -203,6 +203,21 @@ def main():
         if rec.get("workload") == wl:
             traffic = {k: v["traffic_bytes"] for k, v in rec["kernels"].items()}
 
+    # what a plain device-to-device copy reaches on this card (read + write bytes), beside the 8 TB/s peak
+    copy_gbs = None
+    if world == 1:
+        src = torch.empty(1 << 27, dtype=torch.float64, device=device).fill_(1.0)
+        dst = torch.empty_like(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dst.copy_(src)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize(device)
+        copy_gbs = 5 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+
     results = {}
     for variant in (["f64", "fr"] if args.variant == "both" else [args.variant]):
         if variant == "f64":
@@ -239,7 +254,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic.get("k_step_f64" if variant == "f64" else "k_step_fr"),
                          "kernel": "k_step_f64_blocked<u8>" if variant == "f64" else "k_step_fr_raw<u8>",
-                         "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": alg},
+                         "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": alg,
+                         "device_copy_GBs": copy_gbs},
         }
         if variant == "fr":
             results[variant]["roofline"]["form"] = "factored (raw opinions, pre-scaled vector)"
@@ -270,7 +286,8 @@ def main():
         threads = c_oracle.max_threads()
         member = np.ones(n, dtype=np.uint8)
         cpu = {"unit": "edge-iterations/s", "cores": threads, "kind": "port",
-               "sample": "%s, %d iterations, OpenMP over rows, iteration loop only" % (wl, NUM_ITER)}
+               "sample": "%s, %d iterations, OpenMP over rows, iteration loop only; *_1_thread: same graph on one "
+                         "thread (f64 %d iterations, exact variant 4 iterations)" % (wl, NUM_ITER, NUM_ITER)}
         if "f64" in results:
             rc, _o, _l, _r, cnnz, secs = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=NUM_ITER,
                                                                        initial=float(INITIAL), n_threads=threads)
@@ -283,6 +300,15 @@ def main():
             cpu["fr_value"] = cnnz * NUM_ITER / secs
             if "value" not in cpu:
                 cpu["value"] = cpu["fr_value"]
+        # one thread beside it (the reference's converge is single-threaded); the exact variant on 4 iterations
+        if "f64" in results:
+            rc, _o, _l, _r, cnnz, secs = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=NUM_ITER,
+                                                                       initial=float(INITIAL), n_threads=1)
+            cpu["value_1_thread"] = cnnz * NUM_ITER / secs
+        if "fr" in results and wl != "c4":
+            rc, _o, cnnz, secs = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=4,
+                                                             initial=INITIAL, n_threads=1)
+            cpu["fr_value_1_thread"] = cnnz * 4 / secs
 
     if rank == 0:
         head = results.get("f64") or results["fr"]
