@@ -373,6 +373,132 @@ __global__ __launch_bounds__(1024) void k_batch_fr_u8(BatchArgsU8 au) {
     }
 }
 
+// Byte-valued opinions, sets of up to 256 slots: the dense product runs on the matrix cores.
+// With xs_j cut into 32 byte limbs, new_s_i = sum_j v_ji * xs_j is a (32 limbs x sources) by
+// (sources x columns) product of bytes whose 32-bit sums are exact (256 * 255 * 255 < 2^24), i.e.
+// one i8 MFMA tile per 32 columns and 32 sources.  The MFMA multiplies SIGNED bytes, so both
+// operands are stored minus 128 (byte ^ 0x80) and the cross terms are added back:
+//   sum_j v_j x_j = M + 128 * sum_j v_j + 128 * M1,   M = sum_j (v_j-128)(x_j-128),  M1 = sum_j (x_j-128);
+// sum_j v_j is a constant of the column and M1 comes from one more MFMA against a matrix of ones.
+// A peer without valid opinions is a dense row of ones with sum n_valid - 1 here, as in the
+// reference (native.rs:263-278), so there is no separate dangling term.  A lane owns one column:
+// its score and factor stay in registers, the opinion bytes it multiplies stay in registers as
+// MFMA operands for all iterations, and only the 32 x n bytes of xs go through LDS.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+struct BatchArgsM {
+    BatchArgs b;             // vals: n_sets * np * np bytes, [column i][source j], each v_ji ^ 0x80
+    const uint32_t* colsum;  // n_sets * np : sum_j v_ji
+    uint32_t np;             // n rounded up to a multiple of 64; blockDim.x == np
+};
+
+static const uint32_t MFMA_ROW_PAD = 16;   // bytes between limb rows of xs in LDS: spreads the 16-byte operand reads over the banks
+
+template <int KS>   // np / 32
+__global__ __launch_bounds__(KS * 32) void k_batch_fr_mfma(BatchArgsM am) {
+    const BatchArgs& a = am.b;
+    constexpr uint32_t NP = KS * 32, ROW = NP + MFMA_ROW_PAD;
+    __shared__ __attribute__((aligned(16))) uint8_t xsb[2][32 * ROW];
+    __shared__ uint4 red_l[2 * (KS / 2)];
+    __shared__ uint32_t sh_nv[KS / 2];
+    const uint32_t n = a.n, set = blockIdx.x, e = threadIdx.x;
+    const int lane = e & 63, wave = e >> 6, r = lane & 31, h = lane >> 5;
+    uint4* outp = a.out + 2 * (size_t)set * n;
+    if (a.pre_status[set] != ET_OK) {
+        if (e < n) u256_store(outp + 2 * e, u256_zero());
+        if (e == 0) a.status[set] = a.pre_status[set];
+        return;
+    }
+    // operands that never change: the opinion bytes of this lane's two columns (one per 32-column tile of
+    // the wavefront), 16 sources per lane half and k-step
+    const uint8_t* vt = reinterpret_cast<const uint8_t*>(a.vals) + (size_t)set * NP * NP;
+    v4i b0[KS], b1[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        b0[ks] = *reinterpret_cast<const v4i*>(vt + (size_t)(wave * 64 + r) * NP + ks * 32 + 16 * h);
+        b1[ks] = *reinterpret_cast<const v4i*>(vt + (size_t)(wave * 64 + 32 + r) * NP + ks * 32 + 16 * h);
+    }
+    const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
+    const int kc0 = (int)(128u * am.colsum[(size_t)set * NP + wave * 64 + r]);
+    const int kc1 = (int)(128u * am.colsum[(size_t)set * NP + wave * 64 + 32 + r]);
+    const bool is_member = e < n && a.member[(size_t)set * n + e] != 0;
+    const U256 scale = is_member ? u256_load(a.scale + 2 * ((size_t)set * n + e)) : u256_zero();
+    U256 s = is_member ? a.initial : u256_zero();              // native.rs:317
+
+    for (uint32_t it = 0; it < a.num_iter; ++it) {
+        uint8_t* xb = xsb[it & 1];
+        // xs_e = s_e * inv(sum_e) * 2^288 as 32 bytes, one row of LDS per limb
+        const U256 xs = fr_mul_redc288(s, scale);
+#pragma unroll
+        for (int l = 0; l < 32; ++l) xb[l * ROW + e] = (uint8_t)(((xs.v[l >> 2] >> (8 * (l & 3))) & 0xFFu) ^ 0x80u);
+        __syncthreads();
+        v16i acc0 = {0}, acc1 = {0}, acc2 = {0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const v4i x = *reinterpret_cast<const v4i*>(xb + r * ROW + ks * 32 + 16 * h);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, b0[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, b1[ks], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, ones, acc2, 0, 0, 0);
+        }
+        // Register q of a lane is limb (q & 3) + 8 * (q >> 2) + 4 * h of its column: registers 4g..4g+3 are the
+        // four bytes of 32-bit word 2g + h.  Lane half 0 keeps tile 0, lane half 1 keeps tile 1; the words
+        // of the other tile are swapped with lane ^ 32.
+        uint64_t keep[4], give[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint64_t t0 = 0, t1 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m1 = 128 * acc2[4 * g + q];
+                t0 += (uint64_t)(uint32_t)(acc0[4 * g + q] + m1 + kc0) << (8 * q);
+                t1 += (uint64_t)(uint32_t)(acc1[4 * g + q] + m1 + kc1) << (8 * q);
+            }
+            keep[g] = h ? t1 : t0;
+            give[g] = h ? t0 : t1;
+        }
+        Acc10 acc;
+        uint64_t c = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t lo = __shfl_xor((uint32_t)give[g], 32, 64), hi = __shfl_xor((uint32_t)(give[g] >> 32), 32, 64);
+            const uint64_t got = ((uint64_t)hi << 32) | lo;
+            const uint64_t even = h ? got : keep[g], odd = h ? keep[g] : got;
+            c += even;
+            acc.v[2 * g] = (uint32_t)c;
+            c >>= 32;
+            c += odd;
+            acc.v[2 * g + 1] = (uint32_t)c;
+            c >>= 32;
+        }
+        acc.v[8] = (uint32_t)c;
+        acc.v[9] = (uint32_t)(c >> 32);
+        s = is_member ? acc_redc288(acc_from_acc10(acc)) : u256_zero();
+    }
+    // output + conservation check (native.rs:331-334): sum of scores == INITIAL * n_valid
+    if (e < n) u256_store(outp + 2 * e, s);
+    U256 tot = s;
+    uint32_t nv = is_member;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        U256 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o.v[q] = __shfl_xor(tot.v[q], off, 64);
+        tot = fr_add(tot, o);
+        nv += __shfl_xor(nv, off, 64);
+    }
+    if (lane == 0) { u256_store(red_l + 2 * wave, tot); sh_nv[wave] = nv; }
+    __syncthreads();
+    if (e == 0) {
+        U256 t = u256_zero();
+        uint32_t members = 0;
+        for (int w = 0; w < KS / 2; ++w) { t = fr_add(t, u256_load(red_l + 2 * w)); members += sh_nv[w]; }
+        U256 expect = u256_zero();
+        for (uint32_t k = 0; k < members; ++k) expect = fr_add(expect, a.initial);
+        a.status[set] = u256_eq(t, expect) ? ET_OK : ET_E_SUM_MISMATCH;
+    }
+}
+
 static size_t batch_u8_lds_bytes(uint32_t n, uint32_t parts, bool vals_in_lds) {
     size_t b = (8 * (size_t)n + 2 * 16 + 2) * sizeof(uint4) + (size_t)40 * (parts - 1) * n;
     if (vals_in_lds) b += (size_t)n * n;
@@ -383,6 +509,9 @@ struct DeviceBatch {
     int device = -1;
     uint32_t n_sets = 0, n = 0;
     bool vals_u8 = false;
+    bool mfma = false;    // byte opinions and n <= 256: d_vals holds the transposed, sign-shifted matrix
+    uint32_t np = 0;      // n rounded up to a multiple of 64 (mfma only)
+    uint32_t* d_colsum = nullptr;
     void* d_vals = nullptr;
     uint8_t* d_member = nullptr;
     uint8_t* d_dangling = nullptr;
@@ -394,7 +523,7 @@ struct DeviceBatch {
     uint64_t edges = 0;   // sum over sets of n_valid * (n_valid - 1): dense edge count of the reference
     ~DeviceBatch() {
         if (device >= 0) (void)hipSetDevice(device);
-        void* p[] = {d_vals, d_member, d_dangling, d_scale, d_inw, d_pre, d_out, d_status};
+        void* p[] = {d_vals, d_member, d_dangling, d_scale, d_inw, d_pre, d_out, d_status, d_colsum};
         for (void* q : p) if (q) (void)hipFree(q);
     }
 };
@@ -477,7 +606,42 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
     // kernel only has to skip the diagonal
     const size_t cells = rows * n;
     b.vals_u8 = vmax.load() <= 255;
-    if (b.vals_u8) {
+    const char* no_mfma = getenv("ET_BATCH_NO_MFMA");   // measurement knob: the VALU kernel for small byte sets too
+    b.mfma = b.vals_u8 && n <= 256 && !(no_mfma && no_mfma[0] == '1');
+    if (b.mfma) {
+        // [column i][source j] bytes of v_ji - 128, padded to np x np with v = 0; a peer without valid
+        // opinions becomes a row of ones over the other members with factor inv(n_valid - 1) (native.rs:263-278)
+        const uint32_t np = (n + 63) / 64 * 64;
+        b.np = np;
+        std::vector<uint8_t> vt((size_t)n_sets * np * np, 0x80);
+        std::vector<uint32_t> colsum((size_t)n_sets * np, 0);
+        const Fr two576 = Fr::one().pow2k(576);
+        parallel_sets(n_sets, [&](uint32_t s) {
+            if (pre[s] != ET_OK) return;
+            const uint32_t* v = values + (size_t)s * n * n;
+            const uint8_t* m = mem.data() + (size_t)s * n;
+            const uint8_t* dg = dang.data() + (size_t)s * n;
+            uint8_t* o = vt.data() + (size_t)s * np * np;
+            uint32_t* cs = colsum.data() + (size_t)s * np;
+            uint32_t nv = 0;
+            for (uint32_t i = 0; i < n; ++i) nv += m[i];
+            const FrRaw uniform = (Fr::from_u64(nv - 1).invert_or_zero() * two576).to_raw();
+            for (uint32_t j = 0; j < n; ++j) {
+                if (!m[j]) continue;
+                if (dg[j]) scale[(size_t)s * n + j] = uniform;
+                for (uint32_t i = 0; i < n; ++i) {
+                    if (!m[i] || i == j) continue;
+                    const uint32_t x = dg[j] ? 1u : v[(size_t)j * n + i];
+                    o[(size_t)i * np + j] = (uint8_t)(x ^ 0x80u);
+                    cs[i] += x;
+                }
+            }
+        });
+        HIP_TRY_B(hipMalloc(&b.d_vals, vt.size()));
+        HIP_TRY_B(hipMemcpy(b.d_vals, vt.data(), vt.size(), hipMemcpyHostToDevice));
+        HIP_TRY_B(hipMalloc((void**)&b.d_colsum, colsum.size() * 4));
+        HIP_TRY_B(hipMemcpy(b.d_colsum, colsum.data(), colsum.size() * 4, hipMemcpyHostToDevice));
+    } else if (b.vals_u8) {
         std::vector<uint8_t> v8(cells);
         parallel_sets(n_sets, [&](uint32_t s) {
             const uint32_t* v = values + (size_t)s * n * n;
@@ -525,7 +689,16 @@ int et_batch_run_fr_async(et_batch* h, uint32_t num_iterations, uint64_t initial
     a.initial = to_u256b(Fr::from_u128(initial_lo, initial_hi).to_raw());
     const size_t budget = 150 * 1024;
     hipStream_t st = (hipStream_t)stream;
-    if (b.vals_u8) {
+    if (b.mfma) {
+        BatchArgsM am;
+        am.b = a; am.colsum = b.d_colsum; am.np = b.np;
+        switch (b.np / 64) {
+            case 1: hipLaunchKernelGGL((k_batch_fr_mfma<2>), dim3(b.n_sets), dim3(64), 0, st, am); break;
+            case 2: hipLaunchKernelGGL((k_batch_fr_mfma<4>), dim3(b.n_sets), dim3(128), 0, st, am); break;
+            case 3: hipLaunchKernelGGL((k_batch_fr_mfma<6>), dim3(b.n_sets), dim3(192), 0, st, am); break;
+            default: hipLaunchKernelGGL((k_batch_fr_mfma<8>), dim3(b.n_sets), dim3(256), 0, st, am); break;
+        }
+    } else if (b.vals_u8) {
         BatchArgsU8 au;
         au.b = a;
         au.cols = (b.n + 63) / 64 * 64;
