@@ -391,6 +391,7 @@ struct BatchArgsM {
     BatchArgs b;             // vals: n_sets * np * np bytes, [column i][source j], each v_ji ^ 0x80
     const uint32_t* colsum;  // n_sets * np : sum_j v_ji
     uint32_t np;             // n rounded up to a multiple of 64; blockDim.x == np
+    U256 initial_m;          // INITIAL_SCORE * 2^256 mod r
 };
 
 static const uint32_t MFMA_ROW_PAD = 16;   // bytes between limb rows of xs in LDS: spreads the 16-byte operand reads over the banks
@@ -425,11 +426,18 @@ __global__ __launch_bounds__(KS * 32) void k_batch_fr_mfma(BatchArgsM am) {
     const bool is_member = e < n && a.member[(size_t)set * n + e] != 0;
     const U256 scale = is_member ? u256_load(a.scale + 2 * ((size_t)set * n + e)) : u256_zero();
     U256 s = is_member ? a.initial : u256_zero();              // native.rs:317
+    // Between iterations a score is carried as sm = s * 2^256 mod r, below 2^256 but not below r: the column
+    // sum (s * 2^288 as an integer below 2^273) needs ONE Montgomery round to get there, the product with the
+    // factor (inv(sum) * 2^288) eight rounds to come back as xs = s * inv(sum) * 2^288, and only the last
+    // iteration pays the nine rounds to the canonical score.
+    U256 sm = is_member ? am.initial_m : u256_zero();
 
     for (uint32_t it = 0; it < a.num_iter; ++it) {
         uint8_t* xb = xsb[it & 1];
-        // xs_e = s_e * inv(sum_e) * 2^288 as 32 bytes, one row of LDS per limb
-        const U256 xs = fr_mul_redc288(s, scale);
+        // xs_e as 32 bytes, one row of LDS per limb
+        Acc prod = acc_zero();
+        acc_mac(prod, sm, scale);
+        const U256 xs = acc_redc_loose<8>(prod);
 #pragma unroll
         for (int l = 0; l < 32; ++l) xb[l * ROW + e] = (uint8_t)(((xs.v[l >> 2] >> (8 * (l & 3))) & 0xFFu) ^ 0x80u);
         __syncthreads();
@@ -473,7 +481,8 @@ __global__ __launch_bounds__(KS * 32) void k_batch_fr_mfma(BatchArgsM am) {
         }
         acc.v[8] = (uint32_t)c;
         acc.v[9] = (uint32_t)(c >> 32);
-        s = is_member ? acc_redc288(acc_from_acc10(acc)) : u256_zero();
+        if (it + 1 == a.num_iter) s = is_member ? acc_redc288(acc_from_acc10(acc)) : u256_zero();
+        else sm = is_member ? acc_redc_loose<1>(acc_from_acc10(acc)) : u256_zero();
     }
     // output + conservation check (native.rs:331-334): sum of scores == INITIAL * n_valid
     if (e < n) u256_store(outp + 2 * e, s);
@@ -592,8 +601,8 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
             sums[i] = Fr::from_u64(sum);
         }
         fr_batch_invert(sums);
-        const Fr two576 = Fr::one().pow2k(576);
-        for (uint32_t i = 0; i < n; ++i) if (m[i] && !dang[(size_t)s * n + i]) scale[(size_t)s * n + i] = (sums[i] * two576).to_raw();
+        // the plain inverse for now: the power of two it carries depends on the kernel chosen below
+        for (uint32_t i = 0; i < n; ++i) if (m[i] && !dang[(size_t)s * n + i]) scale[(size_t)s * n + i] = sums[i].to_raw();
         inw[s] = (Fr::from_u64(nv - 1).invert_or_zero() * Fr::one().pow2k(288)).to_raw();
         uint32_t cur = vmax.load();
         while (local_max > cur && !vmax.compare_exchange_weak(cur, local_max)) {}
@@ -615,7 +624,6 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
         b.np = np;
         std::vector<uint8_t> vt((size_t)n_sets * np * np, 0x80);
         std::vector<uint32_t> colsum((size_t)n_sets * np, 0);
-        const Fr two576 = Fr::one().pow2k(576);
         parallel_sets(n_sets, [&](uint32_t s) {
             if (pre[s] != ET_OK) return;
             const uint32_t* v = values + (size_t)s * n * n;
@@ -625,10 +633,12 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
             uint32_t* cs = colsum.data() + (size_t)s * np;
             uint32_t nv = 0;
             for (uint32_t i = 0; i < n; ++i) nv += m[i];
-            const FrRaw uniform = (Fr::from_u64(nv - 1).invert_or_zero() * two576).to_raw();
+            // factors carry 2^288: the kernel multiplies them with scores that carry 2^256 and divides by 2^256
+            const FrRaw uniform = Fr::from_u64(nv - 1).invert_or_zero().pow2k(288).to_raw();
             for (uint32_t j = 0; j < n; ++j) {
                 if (!m[j]) continue;
-                if (dg[j]) scale[(size_t)s * n + j] = uniform;
+                FrRaw& f = scale[(size_t)s * n + j];
+                f = dg[j] ? uniform : Fr::from_raw(f).pow2k(288).to_raw();
                 for (uint32_t i = 0; i < n; ++i) {
                     if (!m[i] || i == j) continue;
                     const uint32_t x = dg[j] ? 1u : v[(size_t)j * n + i];
@@ -641,7 +651,16 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
         HIP_TRY_B(hipMemcpy(b.d_vals, vt.data(), vt.size(), hipMemcpyHostToDevice));
         HIP_TRY_B(hipMalloc((void**)&b.d_colsum, colsum.size() * 4));
         HIP_TRY_B(hipMemcpy(b.d_colsum, colsum.data(), colsum.size() * 4, hipMemcpyHostToDevice));
-    } else if (b.vals_u8) {
+    } else {
+        // the vector kernels multiply the factor with a canonical score and divide by 2^288 twice per iteration
+        parallel_sets(n_sets, [&](uint32_t s) {
+            for (uint32_t i = 0; i < n; ++i) {
+                FrRaw& f = scale[(size_t)s * n + i];
+                f = Fr::from_raw(f).pow2k(576).to_raw();
+            }
+        });
+    }
+    if (!b.mfma && b.vals_u8) {
         std::vector<uint8_t> v8(cells);
         parallel_sets(n_sets, [&](uint32_t s) {
             const uint32_t* v = values + (size_t)s * n * n;
@@ -651,7 +670,7 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
         });
         HIP_TRY_B(hipMalloc(&b.d_vals, cells));
         HIP_TRY_B(hipMemcpy(b.d_vals, v8.data(), cells, hipMemcpyHostToDevice));
-    } else {
+    } else if (!b.mfma) {
         std::vector<uint32_t> v32(cells);
         parallel_sets(n_sets, [&](uint32_t s) {
             const uint32_t* v = values + (size_t)s * n * n;
@@ -692,6 +711,7 @@ int et_batch_run_fr_async(et_batch* h, uint32_t num_iterations, uint64_t initial
     if (b.mfma) {
         BatchArgsM am;
         am.b = a; am.colsum = b.d_colsum; am.np = b.np;
+        am.initial_m = to_u256b(Fr::from_u128(initial_lo, initial_hi).pow2k(256).to_raw());
         switch (b.np / 64) {
             case 1: hipLaunchKernelGGL((k_batch_fr_mfma<2>), dim3(b.n_sets), dim3(64), 0, st, am); break;
             case 2: hipLaunchKernelGGL((k_batch_fr_mfma<4>), dim3(b.n_sets), dim3(128), 0, st, am); break;

@@ -221,6 +221,33 @@ ET_DEV U256 acc_redc288(Acc a) {
     return u256_sub_p_if_geq(r);
 }
 
+// acc * 2^-(32 * ROUNDS) mod r for acc < 2^(32 * ROUNDS) * 2^255, NOT brought below r: the result is below 2^256
+// and congruent, which is all a value needs that is only multiplied again.
+template <int ROUNDS>
+ET_DEV U256 acc_redc_loose(Acc a) {
+    static_assert(ROUNDS >= 1 && ROUNDS <= 9, "the accumulator holds 17 limbs");
+    uint32_t carry2 = 0;
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) {
+        uint32_t m = a.v[i] * FR_N0_32;
+        uint64_t t = (uint64_t)m * FR_P[0] + a.v[i];
+        uint64_t c = t >> 32;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            t = (uint64_t)m * FR_P[j] + a.v[i + j] + c;
+            a.v[i + j] = (uint32_t)t;
+            c = t >> 32;
+        }
+        t = (uint64_t)a.v[i + 8] + c + carry2;
+        a.v[i + 8] = (uint32_t)t;
+        carry2 = (uint32_t)(t >> 32);
+    }
+    U256 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = a.v[ROUNDS + i];
+    return r;
+}
+
 // 320-bit accumulator for sums of (32-bit opinion) x (field element): holds 2^34 such products
 struct Acc10 {
     uint32_t v[10];

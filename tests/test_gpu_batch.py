@@ -17,9 +17,34 @@ def dense_expect(values, member, iters, initial):
 
 @pytest.mark.parametrize("n,n_sets,vmax", [(4, 9, 255), (12, 5, 1000), (64, 6, 255), (256, 8, 255), (256, 3, 2**32 - 1),
                                           (300, 2, 255), (700, 1, 70000),
-                                          # byte-valued kernel: uneven column split, matrix left in global memory, >256 sources per part
-                                          (33, 4, 3), (100, 3, 255), (130, 2, 200), (400, 2, 255), (1000, 1, 255)])
+                                          # byte opinions: every tile count of the matrix-core kernel (n <= 256), then the
+                                          # vector kernel with the matrix in LDS / left in global memory, >256 sources per part
+                                          (33, 4, 3), (100, 3, 255), (130, 2, 200), (192, 2, 255), (200, 2, 255),
+                                          (400, 2, 255), (1000, 1, 255)])
 def test_batch_matches_dense_restatement(n, n_sets, vmax):
+    _check_batch(n, n_sets, vmax)
+
+
+@pytest.mark.parametrize("n,n_sets,vmax", [(33, 4, 3), (130, 2, 200), (256, 2, 255)])
+def test_batch_vector_kernel_on_small_byte_sets(n, n_sets, vmax, monkeypatch):
+    # uneven column split of the byte-valued vector kernel, which small sets reach only with the matrix cores switched off
+    monkeypatch.setenv("ET_BATCH_NO_MFMA", "1")
+    _check_batch(n, n_sets, vmax)
+
+
+@pytest.mark.parametrize("n,iters", [(256, 20), (200, 20), (64, 1), (64, 0), (5, 3)])
+def test_batch_extreme_bytes(n, iters):
+    # the largest column sums the byte-limb product can see (every opinion 255), and a 0/255 mix
+    rng = np.random.default_rng(n + iters)
+    values = np.full((2, n, n), 255, dtype=np.uint32)
+    values[1] = rng.integers(0, 2, (n, n), dtype=np.uint32) * 255
+    out, status = pa.Batch(values).converge_fr(iters, 1000)
+    for s in range(2):
+        rc, exp, _ = dense_expect(values[s], np.ones(n, dtype=np.uint8), iters, 1000)
+        assert rc == 0 and status[s] == 0 and pa.fr_ints_from_bytes(out[s]) == exp, (n, s)
+
+
+def _check_batch(n, n_sets, vmax):
     rng = np.random.default_rng(n * 7 + n_sets)
     values = rng.integers(0, vmax + 1, (n_sets, n, n), dtype=np.uint64).astype(np.uint32)
     member = (rng.random((n_sets, n)) > 0.06).astype(np.uint8)
