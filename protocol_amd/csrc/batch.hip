@@ -397,7 +397,7 @@ struct BatchArgsM {
 static const uint32_t MFMA_ROW_PAD = 16;   // bytes between limb rows of xs in LDS: spreads the 16-byte operand reads over the banks
 
 template <int KS>   // np / 32
-__global__ __launch_bounds__(KS * 32) void k_batch_fr_mfma(BatchArgsM am) {
+__global__ __launch_bounds__(KS * 32) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_batch_fr_mfma(BatchArgsM am) {
     const BatchArgs& a = am.b;
     constexpr uint32_t NP = KS * 32, ROW = NP + MFMA_ROW_PAD;
     __shared__ __attribute__((aligned(16))) uint8_t xsb[2][32 * ROW];
