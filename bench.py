@@ -120,7 +120,15 @@ def bench_small_sets(args, world, rank, device, red):
                        "sets": C5_SETS, "slots": C5_SLOTS, "iterations": NUM_ITER, "parallelism": "sets split x%d" % world,
                        "seed": args.seed},
             "sets_per_s": C5_SETS * args.steps / elapsed,
-            "roofline": None, "cpu_baseline": cpu,
+            # the dense product runs as byte-limb i8 MFMA tiles (32 limbs x 256 sources x 256 columns per set and
+            # iteration, plus a third as many against a matrix of ones); i8 dense peak = 2 x bf16.  The launch is
+            # bound by the per-element field arithmetic on the vector ALUs, not by the matrix cores.
+            "roofline": {"bound": "mfma", "achieved": C5_SETS * NUM_ITER * args.steps * 2.0 * 32 * C5_SLOTS * C5_SLOTS / elapsed / 1e12,
+                         "peak": 5000.0, "unit": "TFLOP/s",
+                         "frac": C5_SETS * NUM_ITER * args.steps * 2.0 * 32 * C5_SLOTS * C5_SLOTS / elapsed / 1e12 / 5000.0,
+                         "traffic": None, "kernel": "k_batch_fr_mfma<8>",
+                         "note": "integer ops of the byte-limb product; the kernel's bound is 32-bit VALU field arithmetic"},
+            "cpu_baseline": cpu,
             "checks": {"all_status_ok": ok, "sampled_sets_bit_exact": ok},
             "setup_s": {"create": t_create},
         }), flush=True)
