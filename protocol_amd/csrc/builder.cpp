@@ -24,22 +24,6 @@ struct Pos {  // global sorted row -> (segment, local row, position)
 
 }  // namespace
 
-// host threads for the scatter passes of the builder (the GPU boxes give a process 16 CPUs)
-static unsigned host_threads() {
-    unsigned hw = std::thread::hardware_concurrency();
-    unsigned t = std::max(1u, std::min(16u, hw ? hw : 1u));
-    if (const char* e = getenv("ET_BUILD_THREADS")) t = (unsigned)std::max(1, atoi(e));
-    return t;
-}
-template <typename F>
-static void run_threads(unsigned count, F f) {
-    if (count <= 1) { f(0); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < count; ++t) th.emplace_back([&f, t]() { f(t); });
-    f(0);
-    for (auto& x : th) x.join();
-}
-
 int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::string& err) {
     const uint32_t n = in.n;
     if (n == 0 || (in.n_edges && (!in.from || !in.to)) || ((in.val_u32 != nullptr) == (in.val_fr != nullptr) && in.n_edges)) {

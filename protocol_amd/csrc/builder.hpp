@@ -13,6 +13,9 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <algorithm>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "fr_host.hpp"
@@ -71,5 +74,21 @@ struct HostGraph {
 
 // Returns 0 or a negative ET_E_* code; `err` receives a human-readable reason.
 int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& out, std::string& err);
+
+// host threads for the scatter passes over the edges (the GPU boxes give a process 16 CPUs)
+inline unsigned host_threads() {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned t = std::max(1u, std::min(16u, hw ? hw : 1u));
+    if (const char* e = getenv("ET_BUILD_THREADS")) t = (unsigned)std::max(1, atoi(e));
+    return t;
+}
+template <typename F>
+inline void run_threads(unsigned count, F f) {
+    if (count <= 1) { f(0); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < count; ++t) th.emplace_back([&f, t]() { f(t); });
+    f(0);
+    for (auto& x : th) x.join();
+}
 
 }  // namespace et

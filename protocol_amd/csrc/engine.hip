@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -140,8 +141,15 @@ ET_DEV double wave_sum_f64(double v) {
 // from run to run; the Fr variant is exact.
 // VT = uint8_t / uint32_t: raw form (per edge: source, accumulator slot, opinion);
 // VT = double: weighted form.
+// PACKED (byte opinions): 5 bytes per edge.  A workgroup's list is sorted by source, so the 64
+// consecutive edges one wavefront loads together span a narrow range: the record holds the
+// accumulator slot (low 16 bits) and the source position minus the position of the chunk's first
+// source (high 16 bits), and one base position per 64 edges sits in a side array.
 // ---------------------------------------------------------------------------------------------
 struct StepArgsF64B {
+    const uint32_t* rec;      // PACKED: [edge] slot | (source - chunk base) << 16
+    const uint32_t* cbase;    // PACKED: base position per chunk of 64 edges, workgroup b's chunks start at cptr[b]
+    const uint64_t* cptr;
     const uint64_t* bk_ptr;
     const uint32_t* grp;      // [f64_blocks][f64_rb / BLOCK_GROUP] row group behind each run of accumulator slots, ~0 = none
     const uint32_t* col;
@@ -160,9 +168,10 @@ struct StepArgsF64B {
     uint32_t final_step;
 };
 
-template <typename VT, bool HAS_ALPHA>
+template <typename VT, bool HAS_ALPHA, bool PACKED = false>
 __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     constexpr bool RAW = sizeof(VT) != sizeof(double);
+    static_assert(!PACKED || sizeof(VT) == 1, "packed records carry byte opinions");
     extern __shared__ double acc_l[];
     __shared__ double red[3][16];
     const int lane = threadIdx.x & 63;
@@ -194,22 +203,42 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     // second batch keeps all sixteen within one window of the source range.
     const uint32_t n_batches = (uint32_t)((e1 - e0) / (U * 1024));
     uint64_t e = e0 + threadIdx.x;
-    for (uint32_t k = 0; k < n_batches; ++k, e += U * 1024) {
-        uint32_t c[U];
-        double w[U], xv[U];
-        uint32_t r[U];
+    if (PACKED) {
+        const uint32_t* __restrict__ cb = a.cbase + a.cptr[b];
+        uint32_t chunk = wave;                             // (e - e0) / 64
+        for (uint32_t k = 0; k < n_batches; ++k, e += U * 1024, chunk += U * 16) {
+            uint32_t rc[U], base[U];
+            double w[U], xv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { c[u] = a.col[e + u * 1024]; w[u] = (double)wr[e + u * 1024]; r[u] = a.row[e + u * 1024]; }
+            for (int u = 0; u < U; ++u) { rc[u] = a.rec[e + u * 1024]; w[u] = (double)wr[e + u * 1024]; base[u] = cb[chunk + u * 16]; }
 #pragma unroll
-        for (int u = 0; u < U; ++u) xv[u] = xr[(size_t)(c[u] >> COL_SEG_SHIFT) * stride + (c[u] & COL_LOCAL_MASK)];
+            for (int u = 0; u < U; ++u) xv[u] = xr[(size_t)base[u] + (rc[u] >> 16)];
 #pragma unroll
-        for (int u = 0; u < U; ++u) atomicAdd(&acc_l[r[u]], w[u] * xv[u]);
-        if (k & 1) __syncthreads();
-    }
-    for (; e < e1; e += 1024) {
-        uint32_t c = a.col[e];
-        double xv = xr[(size_t)(c >> COL_SEG_SHIFT) * stride + (c & COL_LOCAL_MASK)];
-        atomicAdd(&acc_l[a.row[e]], (double)wr[e] * xv);
+            for (int u = 0; u < U; ++u) atomicAdd(&acc_l[rc[u] & 0xFFFFu], w[u] * xv[u]);
+            if (k & 1) __syncthreads();
+        }
+        for (; e < e1; e += 1024, chunk += 16) {
+            const uint32_t rc = a.rec[e];
+            atomicAdd(&acc_l[rc & 0xFFFFu], (double)wr[e] * xr[(size_t)cb[chunk] + (rc >> 16)]);
+        }
+    } else {
+        for (uint32_t k = 0; k < n_batches; ++k, e += U * 1024) {
+            uint32_t c[U];
+            double w[U], xv[U];
+            uint32_t r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { c[u] = a.col[e + u * 1024]; w[u] = (double)wr[e + u * 1024]; r[u] = a.row[e + u * 1024]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = xr[(size_t)(c[u] >> COL_SEG_SHIFT) * stride + (c[u] & COL_LOCAL_MASK)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) atomicAdd(&acc_l[r[u]], w[u] * xv[u]);
+            if (k & 1) __syncthreads();
+        }
+        for (; e < e1; e += 1024) {
+            uint32_t c = a.col[e];
+            double xv = xr[(size_t)(c >> COL_SEG_SHIFT) * stride + (c & COL_LOCAL_MASK)];
+            atomicAdd(&acc_l[a.row[e]], (double)wr[e] * xv);
+        }
     }
     __syncthreads();
 
@@ -573,7 +602,7 @@ static int dev_upload(T** p, const std::vector<T>& v, uint64_t& total) {
 
 DeviceGraph::~DeviceGraph() {
     if (device >= 0) (void)hipSetDevice(device);
-    void* ptrs[] = {d_bk_ptr, d_bk_grp, d_bk_col, d_bk_row, d_bk_w, d_work, d_slices, d_col, d_val, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
+    void* ptrs[] = {d_bk_ptr, d_bk_grp, d_bk_col, d_bk_row, d_bk_w, d_bk_rec, d_bk_cbase, d_bk_cptr, d_work, d_slices, d_col, d_val, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
                     d_chg_part, d_stat_out, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust, d_scale64, d_scale_fr, own64, own_fr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* e : ev_begin) (void)hipEventDestroy((hipEvent_t)e);
@@ -638,8 +667,35 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     if (g->variants & ET_VARIANT_F64) {
         g->n_f64_parts = h.geo.f64_blocks;
         const size_t ne = h.bk_col.size();
-        if ((rc = dev_upload(&g->d_bk_ptr, h.bk_ptr, tot)) || (rc = dev_upload(&g->d_bk_grp, h.bk_grp, tot)) ||
-            (rc = dev_upload(&g->d_bk_col, h.bk_col, tot)) || (rc = dev_upload(&g->d_bk_row, h.bk_row, tot))) return rc;
+        if ((rc = dev_upload(&g->d_bk_ptr, h.bk_ptr, tot)) || (rc = dev_upload(&g->d_bk_grp, h.bk_grp, tot))) return rc;
+        // byte opinions: 5-byte edge records (see k_step_f64_blocked) unless a chunk of 64 consecutive edges of a
+        // workgroup spans more than 65535 positions (a few edges over very many peers) or positions need 33 bits
+        if (g->raw && g->val_bytes == 1 && vec_len <= 0xFFFFFFFFull && !getenv("ET_F64_UNPACKED")) {
+            const uint32_t B = h.geo.f64_blocks;
+            std::vector<uint64_t> cptr((size_t)B + 1, 0);
+            for (uint32_t b = 0; b < B; ++b) cptr[b + 1] = cptr[b] + (h.bk_ptr[b + 1] - h.bk_ptr[b] + 63) / 64;
+            std::vector<uint32_t> cbase(cptr[B]), rec(ne);
+            std::atomic<bool> fits(true);
+            run_threads(host_threads(), [&](unsigned t) {
+                const unsigned T = host_threads();
+                for (uint32_t b = (uint32_t)((uint64_t)B * t / T); b < (uint32_t)((uint64_t)B * (t + 1) / T); ++b) {
+                    uint32_t base = 0;
+                    for (uint64_t q = h.bk_ptr[b]; q < h.bk_ptr[b + 1]; ++q) {
+                        const uint32_t pos = h.geo.pos_of_col(h.bk_col[q]);
+                        const uint64_t rel = q - h.bk_ptr[b];
+                        if ((rel & 63) == 0) { base = pos; cbase[cptr[b] + rel / 64] = base; }
+                        if (pos - base > 0xFFFFu) fits = false;
+                        rec[q] = (uint32_t)h.bk_row[q] | ((pos - base) << 16);
+                    }
+                }
+            });
+            if (fits) {
+                g->packed = true;
+                if ((rc = dev_upload(&g->d_bk_rec, rec, tot)) || (rc = dev_upload(&g->d_bk_cbase, cbase, tot)) ||
+                    (rc = dev_upload(&g->d_bk_cptr, cptr, tot))) return rc;
+            }
+        }
+        if (!g->packed && ((rc = dev_upload(&g->d_bk_col, h.bk_col, tot)) || (rc = dev_upload(&g->d_bk_row, h.bk_row, tot)))) return rc;
         if (g->raw) {
             if ((rc = upload_values(&g->d_bk_w, h.bk_val_u32))) return rc;
             if ((rc = dev_alloc(&g->own64, h.geo.rows_cap, tot))) return rc;
@@ -688,7 +744,8 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     // the LDS accumulators may exceed the 64 KiB a kernel may use without opting in
     {
         const int lds_max = 160 * 1024 - 1024;
-        const void* fns[] = {(const void*)k_step_f64_blocked<uint8_t, false>, (const void*)k_step_f64_blocked<uint8_t, true>,
+        const void* fns[] = {(const void*)k_step_f64_blocked<uint8_t, false, true>, (const void*)k_step_f64_blocked<uint8_t, true, true>,
+                             (const void*)k_step_f64_blocked<uint8_t, false>, (const void*)k_step_f64_blocked<uint8_t, true>,
                              (const void*)k_step_f64_blocked<uint32_t, false>, (const void*)k_step_f64_blocked<uint32_t, true>,
                              (const void*)k_step_f64_blocked<double, false>, (const void*)k_step_f64_blocked<double, true>};
         for (const void* f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
@@ -719,10 +776,10 @@ int DeviceGraph::init_fr(uint64_t lo, uint64_t hi, uint4* x, hipStream_t st, boo
     HIP_TRY(hipGetLastError());
     return ET_OK;
 }
-template <typename VT>
+template <typename VT, bool PACKED = false>
 static void launch_f64(const StepArgsF64B& a, unsigned blocks, size_t lds, hipStream_t st) {
-    if (a.alpha != 0.0) hipLaunchKernelGGL((k_step_f64_blocked<VT, true>), dim3(blocks), dim3(1024), lds, st, a);
-    else hipLaunchKernelGGL((k_step_f64_blocked<VT, false>), dim3(blocks), dim3(1024), lds, st, a);
+    if (a.alpha != 0.0) hipLaunchKernelGGL((k_step_f64_blocked<VT, true, PACKED>), dim3(blocks), dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((k_step_f64_blocked<VT, false, PACKED>), dim3(blocks), dim3(1024), lds, st, a);
 }
 int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, uint32_t flags, hipStream_t st) {
     if (!(variants & ET_VARIANT_F64)) { set_error("graph was built without the f64 variant"); return ET_E_UNSUPPORTED; }
@@ -731,11 +788,13 @@ int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double
     const size_t ring = (size_t)(iteration % STATS_RING) * n_f64_parts;
     StepArgsF64B a;
     a.bk_ptr = d_bk_ptr; a.grp = d_bk_grp; a.col = d_bk_col; a.w = d_bk_w; a.row = d_bk_row; a.x = x; a.y = y; a.pretrust = pretrust;
+    a.rec = d_bk_rec; a.cbase = d_bk_cbase; a.cptr = d_bk_cptr;
     a.own = own64; a.scale = d_scale64;
     a.res_part = d_res_part + ring; a.sum_part = d_sum_part + ring;
     a.geo = geo; a.inv_nm1 = inv_nm1; a.alpha = alpha; a.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u;
     const size_t lds = (size_t)geo.f64_rb * sizeof(double);
     if (!raw) launch_f64<double>(a, geo.f64_blocks, lds, st);
+    else if (packed) launch_f64<uint8_t, true>(a, geo.f64_blocks, lds, st);
     else if (val_bytes == 1) launch_f64<uint8_t>(a, geo.f64_blocks, lds, st);
     else launch_f64<uint32_t>(a, geo.f64_blocks, lds, st);
     HIP_TRY(hipGetLastError());

@@ -48,6 +48,12 @@ struct DeviceGraph {
     uint32_t* d_bk_col = nullptr;
     uint16_t* d_bk_row = nullptr;
     void* d_bk_w = nullptr;
+    // byte opinions: d_bk_col / d_bk_row replaced by packed records (slot | source offset << 16) plus one base
+    // position per 64 edges
+    bool packed = false;
+    uint32_t* d_bk_rec = nullptr;
+    uint32_t* d_bk_cbase = nullptr;
+    uint64_t* d_bk_cptr = nullptr;
     uint4* d_wlo = nullptr;
     uint4* d_whi = nullptr;
     uint32_t* d_pos = nullptr;
