@@ -116,6 +116,24 @@ def test_random_graphs_fr_bit_exact_and_f64_close(n, avg, pe, pd, vmax, hub):
     assert abs(res - eres) <= 1e-6 * max(1.0, abs(eres))
 
 
+@pytest.mark.parametrize("n,edges,force", [(400000, 3000, False), (20000, 300000, True)])
+def test_f64_byte_opinions_without_packed_records(n, edges, force, monkeypatch):
+    # the 5-byte edge records hold a 16-bit source offset per 64-edge chunk: a few edges spread over very many
+    # peers do not fit and take the 7-byte records, as does any graph with the measurement knob set
+    if force:
+        monkeypatch.setenv("ET_F64_UNPACKED", "1")
+    rng = np.random.default_rng(n + edges)
+    frm = rng.integers(0, n, edges, dtype=np.uint32)
+    to = rng.integers(0, n, edges, dtype=np.uint32)
+    val = rng.integers(1, 256, edges, dtype=np.uint32)
+    member = np.ones(n, dtype=np.uint8)
+    rc, e64, eld, eres, _, _ = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=20, initial=1000.0, want_ld=True)
+    assert rc == 0
+    g = pa.Graph(n, frm, to, value_u32=val, member=member, variants=2)
+    o64, res = g.converge_f64(20, 1000.0)
+    assert rel_l1(o64, eld) <= F64_TOL
+
+
 def test_field_valued_opinions_bit_exact():
     rng = random.Random(99)
     n = 300
