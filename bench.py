@@ -210,6 +210,12 @@ def main():
             rec = json.load(f)
         if rec.get("workload") == wl:
             traffic = {k: v["traffic_bytes"] for k, v in rec["kernels"].items()}
+            # share of the vector-ALU issue slots the exact kernel used in that profile: wave-instructions x 4 cycles
+            # (a SIMD issues one full-rate wave64 instruction per 4 cycles; the 64-bit multiply-adds take longer, so
+            # this is a lower bound) over 1024 SIMDs x the cycles of the launch
+            fr_rec = rec["kernels"].get("k_step_fr", {})
+            if "SQ_INSTS_VALU" in fr_rec:
+                traffic["fr_valu_issue_frac"] = fr_rec["SQ_INSTS_VALU"] * 4.0 / (1024 * fr_rec["GRBM_GUI_ACTIVE"] / 8.0)
 
     # what a plain device-to-device copy reaches on this card (read + write bytes), beside the 8 TB/s peak
     copy_gbs = None
@@ -266,6 +272,7 @@ def main():
                          "device_copy_GBs": copy_gbs},
         }
         if variant == "fr":
+            results[variant]["roofline"]["valu_issue_frac"] = traffic.get("fr_valu_issue_frac")
             results[variant]["roofline"]["form"] = "factored (raw opinions, pre-scaled vector)"
             results[variant]["roofline"]["weighted_csr_bytes_per_launch"] = int(info.nnz_local) * 36 + rows_local * 68
 
