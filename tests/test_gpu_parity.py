@@ -235,3 +235,21 @@ def test_full_size_benchmark_graph_parity():
                                                          n_threads=c_oracle.max_threads(), want_ld=True)
     o64, _ = g.converge_f64(20, 1000.0)
     assert rel_l1(o64, eld) <= F64_TOL
+
+
+def test_full_size_properties_linearity_and_relabelling():
+    """Size-independent properties on the 1M-peer graph, exact variant: scores are linear in the initial score
+    (native.rs:317-329 has no constant term), and renaming the peers renames the scores."""
+    n = 1 << 20
+    frm, to, val = pa.synth_graph(3, n, 1 << 24, seed=42, value_max=255)
+    g = pa.Graph(n, frm, to, value_u32=val, variants=1)
+    a = pa.fr_ints_from_bytes(g.converge_fr(20, 1000)[:4096])
+    b = pa.fr_ints_from_bytes(g.converge_fr(20, 3000)[:4096])
+    assert [3 * x % R for x in a] == b
+    one = g.converge_fr(20, 1000)
+    rng = np.random.default_rng(11)
+    perm = rng.permutation(n).astype(np.uint32)          # peer i becomes peer perm[i]
+    shuffle = rng.permutation(len(frm))                  # and the attestations arrive in another order
+    g2 = pa.Graph(n, perm[frm][shuffle], perm[to][shuffle], value_u32=val[shuffle], variants=1)
+    two = g2.converge_fr(20, 1000)
+    assert np.array_equal(two[perm], one)
