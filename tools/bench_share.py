@@ -70,6 +70,8 @@ def main():
             out[kind_ + "_us"] = round(us, 1)
             out[kind_ + "_edges_per_s"] = float("%.3g" % (int(info.nnz_local) / (us * 1e-6)))
             del x, y
+        import resource
+        out["host_peak_rss_gib"] = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20, 1)
         print(json.dumps(out), flush=True)
         g.close()
         del g
