@@ -11,8 +11,9 @@
 // x(hash/s * G + r/s * Q) = r whenever it is not the point at infinity, so the sanity check of
 // ecdsa/native.rs:322-327 cannot fail here and is not repeated per lane.
 //
-// All three prime fields (secp256k1 base field p, its scalar field n, bn256 scalar field) use one
-// Montgomery multiplication over 8 x 32-bit limbs with R = 2^256; the moduli live in constant memory.
+// The secp256k1 scalar field n and the bn256 scalar field use one Montgomery multiplication over
+// 8 x 32-bit limbs with R = 2^256, the moduli in constant memory; the secp256k1 base field p, where
+// most of the work is, uses plain residues and the fold 2^256 = 2^32 + 977 (mod p).
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -51,8 +52,8 @@ enum { MOD_P = 0, MOD_N = 1, MOD_R = 2 };
 
 struct RecoverConsts {
     ModConst mod[3];
-    F256 gx, gy;          // generator, Montgomery form mod p
-    F256 seven;           // 7, Montgomery form mod p
+    F256 gx, gy;          // generator, plain form mod p
+    F256 seven;           // 7
     F256 rc[340];         // Poseidon round constants, Montgomery form mod r
     F256 mds[25];
 };
@@ -187,24 +188,128 @@ EC_DEV F256 f_inv(const F256& a, const ModConst& M) {
     return f_pow(a, e, M);
 }
 
-// Jacobian points on y^2 = x^3 + 7 over F_p, Montgomery coordinates; z == 0 is the point at infinity
+// ---- secp256k1 base field, p = 2^256 - 2^32 - 977, plain (non-Montgomery) representation ------------------
+// 2^256 = 2^32 + 977 (mod p): the high half of a 512-bit product folds into the low half with eight
+// multiply-adds by 977 and a one-limb shift, instead of the 64 of a Montgomery reduction.
+EC_DEV F256 fp_reduce512(const uint32_t* t, const ModConst& P) {
+    uint32_t r[10];
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                 // r = lo + hi * 977
+        uint64_t v = (uint64_t)t[8 + j] * 977u + t[j] + c;
+        r[j] = (uint32_t)v;
+        c = v >> 32;
+    }
+    r[8] = (uint32_t)c;
+    c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                 // r += hi << 32
+        uint64_t v = (uint64_t)r[j + 1] + t[8 + j] + c;
+        r[j + 1] = (uint32_t)v;
+        c = v >> 32;
+    }
+    r[9] = (uint32_t)c;                           // 0 or 1
+    // second fold: top = r[8] + r[9] * 2^32 times (2^32 + 977)
+    const uint64_t a0 = (uint64_t)r[8] * 977u;
+    const uint64_t a1 = (uint64_t)r[8] + (uint64_t)r[9] * 977u + (a0 >> 32);
+    uint64_t v = (uint64_t)r[0] + (uint32_t)a0;
+    r[0] = (uint32_t)v; c = v >> 32;
+    v = (uint64_t)r[1] + (uint32_t)a1 + c;
+    r[1] = (uint32_t)v; c = v >> 32;
+    v = (uint64_t)r[2] + (a1 >> 32) + r[9] + c;
+    r[2] = (uint32_t)v; c = v >> 32;
+#pragma unroll
+    for (int j = 3; j < 8; ++j) { v = (uint64_t)r[j] + c; r[j] = (uint32_t)v; c = v >> 32; }
+    // a carry out of 2^256 leaves a tiny remainder: one more 2^32 + 977 cannot carry again
+    const uint32_t k = (uint32_t)c;
+    v = (uint64_t)r[0] + (k ? 977u : 0u);
+    r[0] = (uint32_t)v; c = v >> 32;
+    v = (uint64_t)r[1] + k + c;
+    r[1] = (uint32_t)v; c = v >> 32;
+#pragma unroll
+    for (int j = 2; j < 8; ++j) { v = (uint64_t)r[j] + c; r[j] = (uint32_t)v; c = v >> 32; }
+    F256 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.v[i] = r[i];
+    if (f_geq(o, P.m)) o = f_sub_raw(o, P.m);
+    return o;
+}
+EC_DEV F256 fp_mul(const F256& a, const F256& b, const ModConst& P) {
+    uint32_t t[16];
+    {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { uint64_t v = (uint64_t)a.v[j] * b.v[0] + c; t[j] = (uint32_t)v; c = v >> 32; }
+        t[8] = (uint32_t)c;
+    }
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { uint64_t v = (uint64_t)a.v[j] * b.v[i] + t[i + j] + c; t[i + j] = (uint32_t)v; c = v >> 32; }
+        t[i + 8] = (uint32_t)c;
+    }
+    return fp_reduce512(t, P);
+}
+EC_DEV F256 fp_sqr(const F256& a, const ModConst& P) {
+    uint32_t t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {                 // products of distinct limbs, once
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = i + 1; j < 8; ++j) { uint64_t v = (uint64_t)a.v[i] * a.v[j] + t[i + j] + c; t[i + j] = (uint32_t)v; c = v >> 32; }
+        t[i + 8] = (uint32_t)c;
+    }
+    uint32_t top = 0;
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const uint32_t nv = (t[k] << 1) | top; top = t[k] >> 31; t[k] = nv; }   // twice
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                 // plus the squares
+        uint64_t v = (uint64_t)a.v[i] * a.v[i] + t[2 * i] + c;
+        t[2 * i] = (uint32_t)v;
+        v = (uint64_t)t[2 * i + 1] + (v >> 32);
+        t[2 * i + 1] = (uint32_t)v;
+        c = v >> 32;
+    }
+    return fp_reduce512(t, P);
+}
+EC_DEV F256 fp_pow(const F256& a, const F256& e, const ModConst& P) {
+    F256 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = i == 0 ? 1u : 0u;
+    for (int i = 255; i >= 0; --i) {
+        r = fp_sqr(r, P);
+        if ((e.v[i >> 5] >> (i & 31)) & 1) r = fp_mul(r, a, P);
+    }
+    return r;
+}
+EC_DEV F256 fp_inv(const F256& a, const ModConst& P) {
+    F256 e = f_load_mod(P.m);   // p - 2: p ends in ...2f, no borrow past limb 0
+    e.v[0] -= 2;
+    return fp_pow(a, e, P);
+}
+
+// Jacobian points on y^2 = x^3 + 7 over F_p, plain coordinates; z == 0 is the point at infinity
 struct JPt {
     F256 x, y, z;
 };
 EC_DEV JPt j_double(const JPt& p, const ModConst& P) {
     if (f_is_zero(p.z) || f_is_zero(p.y)) { JPt o = p; for (int i = 0; i < 8; ++i) o.z.v[i] = 0; return o; }
-    F256 a = f_mul(p.x, p.x, P), b = f_mul(p.y, p.y, P), c = f_mul(b, b, P);
+    F256 a = fp_sqr(p.x, P), b = fp_sqr(p.y, P), c = fp_sqr(b, P);
     F256 t = f_add(p.x, b, P);
-    F256 d = f_sub(f_sub(f_mul(t, t, P), a, P), c, P);
+    F256 d = f_sub(f_sub(fp_sqr(t, P), a, P), c, P);
     d = f_add(d, d, P);
-    F256 e = f_add(f_add(a, a, P), a, P), f = f_mul(e, e, P);
+    F256 e = f_add(f_add(a, a, P), a, P), f = fp_sqr(e, P);
     JPt r;
     r.x = f_sub(f, f_add(d, d, P), P);
     F256 c8 = f_add(c, c, P);
     c8 = f_add(c8, c8, P);
     c8 = f_add(c8, c8, P);
-    r.y = f_sub(f_mul(e, f_sub(d, r.x, P), P), c8, P);
-    F256 yz = f_mul(p.y, p.z, P);
+    r.y = f_sub(fp_mul(e, f_sub(d, r.x, P), P), c8, P);
+    F256 yz = fp_mul(p.y, p.z, P);
     r.z = f_add(yz, yz, P);
     return r;
 }
@@ -212,11 +317,13 @@ EC_DEV JPt j_double(const JPt& p, const ModConst& P) {
 EC_DEV JPt j_add_affine(const JPt& p, const F256& qx, const F256& qy, const ModConst& P) {
     if (f_is_zero(p.z)) {
         JPt o;
-        o.x = qx; o.y = qy; o.z = f_load_mod(P.one);
+        o.x = qx; o.y = qy;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.z.v[i] = i == 0 ? 1u : 0u;
         return o;
     }
-    F256 z1z1 = f_mul(p.z, p.z, P);
-    F256 u2 = f_mul(qx, z1z1, P), s2 = f_mul(f_mul(qy, p.z, P), z1z1, P);
+    F256 z1z1 = fp_sqr(p.z, P);
+    F256 u2 = fp_mul(qx, z1z1, P), s2 = fp_mul(fp_mul(qy, p.z, P), z1z1, P);
     if (f_eq(p.x, u2)) {
         if (f_eq(p.y, s2)) return j_double(p, P);
         JPt o = p;
@@ -224,11 +331,11 @@ EC_DEV JPt j_add_affine(const JPt& p, const F256& qx, const F256& qy, const ModC
         return o;
     }
     F256 h = f_sub(u2, p.x, P), r = f_sub(s2, p.y, P);
-    F256 hh = f_mul(h, h, P), hhh = f_mul(hh, h, P), v = f_mul(p.x, hh, P);
+    F256 hh = fp_sqr(h, P), hhh = fp_mul(hh, h, P), v = fp_mul(p.x, hh, P);
     JPt o;
-    o.x = f_sub(f_sub(f_mul(r, r, P), hhh, P), f_add(v, v, P), P);
-    o.y = f_sub(f_mul(r, f_sub(v, o.x, P), P), f_mul(p.y, hhh, P), P);
-    o.z = f_mul(p.z, h, P);
+    o.x = f_sub(f_sub(fp_sqr(r, P), hhh, P), f_add(v, v, P), P);
+    o.y = f_sub(fp_mul(r, f_sub(v, o.x, P), P), fp_mul(p.y, hhh, P), P);
+    o.z = fp_mul(p.z, h, P);
     return o;
 }
 
@@ -327,8 +434,8 @@ EC_DEV void recover_lane(const uint8_t* rec, const RecoverConsts* K, uint8_t* ou
     if (f_is_zero(r) || f_is_zero(s) || f_geq(r, N.m) || f_geq(s, N.m)) code = REC_BAD_SCALAR;
 
     // ---- R = (r, y): y = (r^3 + 7)^((p + 1) / 4) ------------------------------------------------------
-    F256 rx = f_to_mont(r, P);
-    F256 rhs = f_add(f_mul(f_mul(rx, rx, P), rx, P), K->seven, P);
+    const F256 rx = r;   // r < n < p
+    F256 rhs = f_add(fp_mul(fp_sqr(rx, P), rx, P), K->seven, P);
     F256 e;
     {
         // (p + 1) / 4: p + 1 does not carry out of 256 bits
@@ -339,9 +446,9 @@ EC_DEV void recover_lane(const uint8_t* rec, const RecoverConsts* K, uint8_t* ou
 #pragma unroll
         for (int k = 0; k < 8; ++k) e.v[k] = (p1[k] >> 2) | (k < 7 ? p1[k + 1] << 30 : 0u);
     }
-    F256 ry = f_pow(rhs, e, P);
-    if (code == REC_OK && !f_eq(f_mul(ry, ry, P), rhs)) code = REC_NOT_ON_CURVE;
-    if ((f_from_mont(ry, P).v[0] & 1u) != (y_odd ? 1u : 0u)) ry = f_sub(f_load_mod(P.m), ry, P);   // p - y (y != 0 on this curve)
+    F256 ry = fp_pow(rhs, e, P);
+    if (code == REC_OK && !f_eq(fp_sqr(ry, P), rhs)) code = REC_NOT_ON_CURVE;
+    if ((ry.v[0] & 1u) != (y_odd ? 1u : 0u)) ry = f_sub(f_load_mod(P.m), ry, P);   // p - y (y != 0 on this curve)
 
     // ---- Q = u1 * G + u2 * R,  u1 = -hash / r,  u2 = s / r  (mod n) -----------------------------------------
     F256 ri = f_inv(f_to_mont(r, N), N);
@@ -351,15 +458,15 @@ EC_DEV void recover_lane(const uint8_t* rec, const RecoverConsts* K, uint8_t* ou
     F256 u1 = f_from_mont(f_sub(zero, f_mul(ri, f_to_mont(hash, N), N), N), N);
     F256 u2 = f_from_mont(f_mul(ri, f_to_mont(s, N), N), N);
     JPt acc;
-    acc.x = zero; acc.y = f_load_mod(P.one); acc.z = zero;
+    acc.x = zero; acc.y = zero; acc.y.v[0] = 1; acc.z = zero;
     for (int bit = 255; bit >= 0; --bit) {
         acc = j_double(acc, P);
         if ((u1.v[bit >> 5] >> (bit & 31)) & 1) acc = j_add_affine(acc, K->gx, K->gy, P);
         if ((u2.v[bit >> 5] >> (bit & 31)) & 1) acc = j_add_affine(acc, rx, ry, P);
     }
     if (code == REC_OK && f_is_zero(acc.z)) code = REC_INFINITY;
-    F256 zi = f_inv(acc.z, P), zi2 = f_mul(zi, zi, P);
-    F256 qx = f_from_mont(f_mul(acc.x, zi2, P), P), qy = f_from_mont(f_mul(acc.y, f_mul(zi2, zi, P), P), P);
+    F256 zi = fp_inv(acc.z, P), zi2 = fp_sqr(zi, P);
+    F256 qx = fp_mul(acc.x, zi2, P), qy = fp_mul(acc.y, fp_mul(zi2, zi, P), P);
 
     // ---- address = Keccak-256(x || y big-endian)[12..32] ---------------------------------------------------
     uint64_t ks[25];
@@ -409,17 +516,17 @@ static void fill_mod(ModConst& mc, const U256h& m) {
 }
 
 
-// the three moduli, the generator, Poseidon's parameters, all in Montgomery form (R = 2^256)
+// the three moduli, the generator (plain), Poseidon's parameters in Montgomery form (R = 2^256)
 static int build_consts(RecoverConsts& K) {
     U256h rmod;
     std::memcpy(rmod.l, FR_MOD, 32);
     fill_mod(K.mod[MOD_P], SECP_P);
     fill_mod(K.mod[MOD_N], SECP_N);
     fill_mod(K.mod[MOD_R], rmod);
-    Mont MP(SECP_P), MR(rmod);
-    put(K.gx.v, MP.to(SECP_GX));
-    put(K.gy.v, MP.to(SECP_GY));
-    put(K.seven.v, MP.to(U256h{{7, 0, 0, 0}}));
+    Mont MR(rmod);
+    put(K.gx.v, SECP_GX);
+    put(K.gy.v, SECP_GY);
+    put(K.seven.v, U256h{{7, 0, 0, 0}});
     std::vector<FrRaw> rc, mds;
     poseidon5_parameters(rc, mds);
     if (rc.size() != 340 || mds.size() != 25) { set_error("internal: Poseidon parameter count"); return ET_E_UNSUPPORTED; }
