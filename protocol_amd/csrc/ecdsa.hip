@@ -160,6 +160,66 @@ EC_DEV F256 f_mul(const F256& a, const F256& b, const ModConst& M) {
     if (t[8] || f_geq(r, M.m)) r = f_sub_raw(r, M.m);
     return r;
 }
+// sum_{k<5} a[k] * b[k] * 2^-256 mod m: the five products are added unreduced (5 m^2 < 2^515 fits 17 limbs)
+// and reduced once -- one Montgomery reduction per row of the Poseidon matrix instead of five
+EC_DEV F256 f_dot5(const F256* a, const F256* b, const ModConst& M) {
+    uint32_t t[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) t[i] = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint64_t c = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint64_t v = (uint64_t)a[k].v[j] * b[k].v[i] + t[i + j] + c;
+                t[i + j] = (uint32_t)v;
+                c = v >> 32;
+            }
+#pragma unroll
+            for (int j = i + 8; j < 17; ++j) {
+                uint64_t v = (uint64_t)t[j] + c;
+                t[j] = (uint32_t)v;
+                c = v >> 32;
+            }
+        }
+    }
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t q = t[i] * M.n0;
+        uint64_t v = (uint64_t)q * M.m[0] + t[i];
+        uint64_t c = v >> 32;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            v = (uint64_t)q * M.m[j] + t[i + j] + c;
+            t[i + j] = (uint32_t)v;
+            c = v >> 32;
+        }
+        v = (uint64_t)t[i + 8] + c + carry;
+        t[i + 8] = (uint32_t)v;
+        carry = (uint32_t)(v >> 32);
+    }
+    // the quotient is below 5 m^2 / 2^256 + m < 3 m for the moduli here (m < 2^254) and fits nine limbs
+    F256 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = t[8 + i];
+    uint32_t hi = t[16] + carry;
+    for (int k = 0; k < 3; ++k) {
+        if (hi || f_geq(r, M.m)) {
+            uint64_t br = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint64_t d = (uint64_t)r.v[i] - M.m[i] - br;
+                r.v[i] = (uint32_t)d;
+                br = (d >> 32) & 1;
+            }
+            hi -= (uint32_t)br;
+        }
+    }
+    return r;
+}
 EC_DEV F256 f_load_mod(const uint32_t* p) {
     F256 r;
 #pragma unroll
@@ -411,11 +471,7 @@ EC_DEV void recover_lane(const uint8_t* rec, const RecoverConsts* K, uint8_t* ou
             st[0] = f_mul(f_mul(x2, x2, R), st[0], R);
         }
         F256 o[5];
-        for (int a = 0; a < 5; ++a) {
-            F256 acc = f_mul(K->mds[a * 5], st[0], R);
-            for (int b = 1; b < 5; ++b) acc = f_add(acc, f_mul(K->mds[a * 5 + b], st[b], R), R);
-            o[a] = acc;
-        }
+        for (int a = 0; a < 5; ++a) o[a] = f_dot5(K->mds + a * 5, st, R);
 #pragma unroll
         for (int k = 0; k < 5; ++k) st[k] = o[k];
     }
