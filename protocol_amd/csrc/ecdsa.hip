@@ -436,7 +436,7 @@ EC_DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 // status codes per record
 enum { REC_OK = 0, REC_BAD_SCALAR = 1, REC_NOT_ON_CURVE = 2, REC_INFINITY = 3 };
 
-EC_DEV void recover_lane(const uint8_t* rec, const RecoverConsts* K, uint8_t* out, uint32_t* ko, uint8_t* status_out) {
+EC_DEV void recover_lane(const uint8_t* rec, const RecoverConsts* K, const F256* gtab, uint8_t* out, uint32_t* ko, uint8_t* status_out) {
     const ModConst& P = K->mod[MOD_P];
     const ModConst& N = K->mod[MOD_N];
     const ModConst& R = K->mod[MOD_R];
@@ -515,10 +515,16 @@ EC_DEV void recover_lane(const uint8_t* rec, const RecoverConsts* K, uint8_t* ou
     F256 u2 = f_from_mont(f_mul(ri, f_to_mont(s, N), N), N);
     JPt acc;
     acc.x = zero; acc.y = zero; acc.y.v[0] = 1; acc.z = zero;
-    for (int bit = 255; bit >= 0; --bit) {
+    for (int bit = 255; bit >= 0; --bit) {            // u2 * R: double and add
         acc = j_double(acc, P);
-        if ((u1.v[bit >> 5] >> (bit & 31)) & 1) acc = j_add_affine(acc, K->gx, K->gy, P);
         if ((u2.v[bit >> 5] >> (bit & 31)) & 1) acc = j_add_affine(acc, rx, ry, P);
+    }
+    for (int w = 0; w < 32; ++w) {                    // u1 * G: one table entry per byte of u1, no doublings
+        const uint32_t d = (u1.v[w >> 2] >> (8 * (w & 3))) & 0xFFu;
+        if (d) {
+            const F256* e = gtab + 2 * ((size_t)w * 256 + d);
+            acc = j_add_affine(acc, e[0], e[1], P);
+        }
     }
     if (code == REC_OK && f_is_zero(acc.z)) code = REC_INFINITY;
     F256 zi = fp_inv(acc.z, P), zi2 = fp_sqr(zi, P);
@@ -551,11 +557,12 @@ EC_DEV void recover_lane(const uint8_t* rec, const RecoverConsts* K, uint8_t* ou
 }
 
 __global__ __launch_bounds__(256) void k_recover(const uint8_t* __restrict__ recs, uint32_t n, const RecoverConsts* __restrict__ K,
-                                                 uint8_t* __restrict__ attesters, uint8_t* __restrict__ keys, uint8_t* __restrict__ status) {
+                                                 const F256* __restrict__ gtab, uint8_t* __restrict__ attesters,
+                                                 uint8_t* __restrict__ keys, uint8_t* __restrict__ status) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // record layout: about[20] domain[20] value message[32] sig_r[32] sig_s[32] rec_id
-    recover_lane(recs + (size_t)i * sizeof(et_attestation), K, attesters + (size_t)i * 20,
+    recover_lane(recs + (size_t)i * sizeof(et_attestation), K, gtab, attesters + (size_t)i * 20,
                  keys ? reinterpret_cast<uint32_t*>(keys + (size_t)i * 64) : nullptr, status + i);
 }
 
@@ -591,6 +598,50 @@ static int build_consts(RecoverConsts& K) {
     return ET_OK;
 }
 
+// Fixed-base table for the generator: entry [w][d] = d * 2^(8w) * G in affine plain coordinates (x, y), d = 1..255
+// (entry 0 unused), 32 windows: u1 * G is the sum of one entry per byte of u1.  Built once per process with the
+// lane arithmetic itself; the Jacobian results are brought to affine form with one shared inversion.
+static const std::vector<F256>& generator_table(const RecoverConsts& K) {
+    static std::vector<F256> table;
+    static std::once_flag once;
+    std::call_once(once, [&]() {
+        const ModConst& P = K.mod[MOD_P];
+        std::vector<JPt> pts((size_t)32 * 256);
+        F256 bx = K.gx, by = K.gy;
+        F256 one;
+        for (int i = 0; i < 8; ++i) one.v[i] = i == 0 ? 1u : 0u;
+        for (int w = 0; w < 32; ++w) {
+            JPt acc;
+            acc.x = bx; acc.y = by; acc.z = one;
+            pts[(size_t)w * 256 + 1] = acc;
+            for (int d = 2; d < 256; ++d) { acc = j_add_affine(acc, bx, by, P); pts[(size_t)w * 256 + d] = acc; }
+            acc = j_add_affine(acc, bx, by, P);            // 256 * base = the next window's base
+            const F256 zi = fp_inv(acc.z, P), zi2 = fp_sqr(zi, P);
+            bx = fp_mul(acc.x, zi2, P);
+            by = fp_mul(acc.y, fp_mul(zi2, zi, P), P);
+        }
+        // batch inversion of every z (none is zero: d * 2^(8w) is never a multiple of the group order)
+        std::vector<F256> prefix(pts.size());
+        F256 run = one;
+        for (size_t i = 0; i < pts.size(); ++i) {
+            if ((i & 255) == 0) { prefix[i] = run; continue; }
+            prefix[i] = run;
+            run = fp_mul(run, pts[i].z, P);
+        }
+        F256 inv = fp_inv(run, P);
+        table.assign(pts.size() * 2, F256{});
+        for (size_t i = pts.size(); i-- > 0;) {
+            if ((i & 255) == 0) continue;
+            const F256 zi = fp_mul(inv, prefix[i], P);
+            inv = fp_mul(inv, pts[i].z, P);
+            const F256 zi2 = fp_sqr(zi, P);
+            table[2 * i] = fp_mul(pts[i].x, zi2, P);
+            table[2 * i + 1] = fp_mul(pts[i].y, fp_mul(zi2, zi, P), P);
+        }
+    });
+    return table;
+}
+
 }  // namespace et
 
 using namespace et;
@@ -612,6 +663,9 @@ extern "C" int et_attestations_recover_gpu(const et_attestation* atts, size_t n,
 
     uint8_t *d_recs = nullptr, *d_addr = nullptr, *d_keys = nullptr, *d_status = nullptr;
     RecoverConsts* d_k = nullptr;
+    F256* d_tab = nullptr;
+    struct FreeTab { F256** t; ~FreeTab() { if (*t) (void)hipFree(*t); } } guard_tab{&d_tab};
+    const std::vector<F256>& tab = generator_table(K);
     struct Free { uint8_t** a; uint8_t** b; uint8_t** c; uint8_t** d; RecoverConsts** k;
                   ~Free() { if (*a) (void)hipFree(*a); if (*b) (void)hipFree(*b); if (*c) (void)hipFree(*c); if (*d) (void)hipFree(*d); if (*k) (void)hipFree(*k); } }
         guard{&d_recs, &d_addr, &d_keys, &d_status, &d_k};
@@ -622,7 +676,9 @@ extern "C" int et_attestations_recover_gpu(const et_attestation* atts, size_t n,
     HIP_TRY_E(hipMalloc((void**)&d_k, sizeof(RecoverConsts)));
     HIP_TRY_E(hipMemcpy(d_recs, atts, n * sizeof(et_attestation), hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemcpy(d_k, &K, sizeof(RecoverConsts), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_recover, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_recs, (uint32_t)n, d_k, d_addr, d_keys, d_status);
+    HIP_TRY_E(hipMalloc((void**)&d_tab, tab.size() * sizeof(F256)));
+    HIP_TRY_E(hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(F256), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_recover, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_recs, (uint32_t)n, d_k, d_tab, d_addr, d_keys, d_status);
     HIP_TRY_E(hipGetLastError());
     std::vector<uint8_t> st(n);
     HIP_TRY_E(hipMemcpy(st.data(), d_status, n, hipMemcpyDeviceToHost));
@@ -648,7 +704,7 @@ extern "C" int et_attestation_recover_lane_host(const et_attestation* att, uint8
     if (rc) return rc;
     uint8_t status = 0;
     uint32_t key[16];
-    recover_lane(reinterpret_cast<const uint8_t*>(att), &kc[0], attester, key, &status);
+    recover_lane(reinterpret_cast<const uint8_t*>(att), &kc[0], generator_table(kc[0]).data(), attester, key, &status);
     std::memcpy(public_key, key, 64);
     if (status != REC_OK) { set_error("lane status " + std::to_string((int)status)); return ET_E_BAD_SIGNATURE; }
     return ET_OK;
