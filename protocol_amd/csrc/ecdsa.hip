@@ -336,20 +336,44 @@ EC_DEV F256 fp_sqr(const F256& a, const ModConst& P) {
     }
     return fp_reduce512(t, P);
 }
-EC_DEV F256 fp_pow(const F256& a, const F256& e, const ModConst& P) {
-    F256 r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = i == 0 ? 1u : 0u;
-    for (int i = 255; i >= 0; --i) {
-        r = fp_sqr(r, P);
-        if ((e.v[i >> 5] >> (i & 31)) & 1) r = fp_mul(r, a, P);
-    }
-    return r;
+EC_DEV F256 fp_sqr_n(F256 a, int n, const ModConst& P) {
+    for (int i = 0; i < n; ++i) a = fp_sqr(a, P);
+    return a;
 }
+// a^(2^223 - 1) and, on the way, a^(2^22 - 1), a^3: the exponents p - 2 and (p + 1) / 4 are 223 ones, a zero,
+// 22 ones and a short tail, so both powers take 255 squarings and 15 multiplications
+struct FpLadder {
+    F256 x2, x22, x223;
+};
+EC_DEV FpLadder fp_ladder(const F256& a, const ModConst& P) {
+    FpLadder L;
+    L.x2 = fp_mul(fp_sqr(a, P), a, P);
+    const F256 x3 = fp_mul(fp_sqr(L.x2, P), a, P);
+    const F256 x6 = fp_mul(fp_sqr_n(x3, 3, P), x3, P);
+    const F256 x9 = fp_mul(fp_sqr_n(x6, 3, P), x3, P);
+    const F256 x11 = fp_mul(fp_sqr_n(x9, 2, P), L.x2, P);
+    L.x22 = fp_mul(fp_sqr_n(x11, 11, P), x11, P);
+    const F256 x44 = fp_mul(fp_sqr_n(L.x22, 22, P), L.x22, P);
+    const F256 x88 = fp_mul(fp_sqr_n(x44, 44, P), x44, P);
+    const F256 x176 = fp_mul(fp_sqr_n(x88, 88, P), x88, P);
+    const F256 x220 = fp_mul(fp_sqr_n(x176, 44, P), x44, P);
+    L.x223 = fp_mul(fp_sqr_n(x220, 3, P), x3, P);
+    return L;
+}
+// a^(p - 2): p - 2 = [223 ones] 0 [22 ones] 0000 1 0 11 0 1
 EC_DEV F256 fp_inv(const F256& a, const ModConst& P) {
-    F256 e = f_load_mod(P.m);   // p - 2: p ends in ...2f, no borrow past limb 0
-    e.v[0] -= 2;
-    return fp_pow(a, e, P);
+    const FpLadder L = fp_ladder(a, P);
+    F256 t = fp_mul(fp_sqr_n(L.x223, 23, P), L.x22, P);
+    t = fp_mul(fp_sqr_n(t, 5, P), a, P);
+    t = fp_mul(fp_sqr_n(t, 3, P), L.x2, P);
+    return fp_mul(fp_sqr_n(t, 2, P), a, P);
+}
+// a^((p + 1) / 4), a square root of a when it has one: (p + 1) / 4 = [223 ones] 0 [22 ones] 0000 11 00
+EC_DEV F256 fp_sqrt(const F256& a, const ModConst& P) {
+    const FpLadder L = fp_ladder(a, P);
+    F256 t = fp_mul(fp_sqr_n(L.x223, 23, P), L.x22, P);
+    t = fp_mul(fp_sqr_n(t, 6, P), L.x2, P);
+    return fp_sqr_n(t, 2, P);
 }
 
 // Jacobian points on y^2 = x^3 + 7 over F_p, plain coordinates; z == 0 is the point at infinity
@@ -492,17 +516,7 @@ EC_DEV void recover_lane(const uint8_t* rec, const RecoverConsts* K, const F256*
     // ---- R = (r, y): y = (r^3 + 7)^((p + 1) / 4) ------------------------------------------------------
     const F256 rx = r;   // r < n < p
     F256 rhs = f_add(fp_mul(fp_sqr(rx, P), rx, P), K->seven, P);
-    F256 e;
-    {
-        // (p + 1) / 4: p + 1 does not carry out of 256 bits
-        uint64_t c = 1;
-        uint32_t p1[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { uint64_t t = (uint64_t)P.m[k] + c; p1[k] = (uint32_t)t; c = t >> 32; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) e.v[k] = (p1[k] >> 2) | (k < 7 ? p1[k + 1] << 30 : 0u);
-    }
-    F256 ry = fp_pow(rhs, e, P);
+    F256 ry = fp_sqrt(rhs, P);
     if (code == REC_OK && !f_eq(fp_sqr(ry, P), rhs)) code = REC_NOT_ON_CURVE;
     if ((ry.v[0] & 1u) != (y_odd ? 1u : 0u)) ry = f_sub(f_load_mod(P.m), ry, P);   // p - y (y != 0 on this curve)
 
