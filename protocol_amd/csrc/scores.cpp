@@ -7,6 +7,7 @@
 // The scores themselves come from the GPU through the set API (et_set_converge); only the exact
 // fractions (et_set_converge_rational) and the bookkeeping here run on the host.
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <cstdio>
 #include <cstring>
@@ -427,14 +428,54 @@ int et_scores_from_attestations(const et_attestation* atts, size_t n_att, const 
     std::vector<uint8_t> who(20 * std::max<size_t>(1, n_att));
     int rc = et_attestations_recover_gpu(atts, n_att, who.data(), nullptr, -1);
     if (rc) return rc;
-    // participants in ascending address order (the BTreeSet of lib.rs:344-361)
-    std::vector<Addr> parts(2 * n_att);
-    for (size_t k = 0; k < n_att; ++k) {
-        std::memcpy(parts[2 * k].data(), atts[k].about, 20);
-        std::memcpy(parts[2 * k + 1].data(), who.data() + 20 * k, 20);
+    // participants in ascending address order (the BTreeSet of lib.rs:344-361).  Addresses are hashes, so their
+    // first byte splits them into 256 even buckets whose concatenation is the sorted order: scatter, then sort and
+    // deduplicate the buckets on the host threads.
+    const unsigned T = host_threads();
+    const size_t n_all = 2 * n_att;
+    auto addr_of = [&](size_t i) -> const uint8_t* { return (i & 1) ? who.data() + 20 * (i >> 1) : atts[i >> 1].about; };
+    std::vector<size_t> cnt((size_t)T * 256, 0);
+    run_threads(T, [&](unsigned t) {
+        size_t* c = cnt.data() + (size_t)t * 256;
+        for (size_t i = n_all * t / T; i < n_all * (t + 1) / T; ++i) ++c[addr_of(i)[0]];
+    });
+    std::vector<size_t> bucket_begin(257, 0);
+    {
+        size_t run = 0;
+        for (unsigned b = 0; b < 256; ++b) {
+            bucket_begin[b] = run;
+            for (unsigned t = 0; t < T; ++t) { const size_t c = cnt[(size_t)t * 256 + b]; cnt[(size_t)t * 256 + b] = run; run += c; }
+        }
+        bucket_begin[256] = run;
     }
-    std::sort(parts.begin(), parts.end());
-    parts.erase(std::unique(parts.begin(), parts.end()), parts.end());
+    std::vector<Addr> all(n_all);
+    run_threads(T, [&](unsigned t) {
+        size_t* c = cnt.data() + (size_t)t * 256;
+        for (size_t i = n_all * t / T; i < n_all * (t + 1) / T; ++i) {
+            const uint8_t* a = addr_of(i);
+            std::memcpy(all[c[a[0]]++].data(), a, 20);
+        }
+    });
+    std::vector<size_t> uniq(257, 0);
+    {
+        std::atomic<unsigned> next(0);
+        run_threads(T, [&](unsigned) {
+            for (;;) {
+                const unsigned b = next.fetch_add(1);
+                if (b >= 256) break;
+                auto first = all.begin() + bucket_begin[b], last = all.begin() + bucket_begin[b + 1];
+                std::sort(first, last);
+                uniq[b + 1] = (size_t)(std::unique(first, last) - first);
+            }
+        });
+    }
+    for (unsigned b = 0; b < 256; ++b) uniq[b + 1] += uniq[b];    // uniq[b] = first participant of bucket b
+    std::vector<Addr> parts(uniq[256]);
+    run_threads(T, [&](unsigned t) {
+        for (unsigned b = 256 * t / T; b < 256 * (t + 1) / T; ++b)
+            std::copy(all.begin() + bucket_begin[b], all.begin() + bucket_begin[b] + (uniq[b + 1] - uniq[b]), parts.begin() + uniq[b]);
+    });
+    { std::vector<Addr>().swap(all); }
     *n_participants = parts.size();
     if (parts.size() < 2) { set_error("Number of participants is less than the minimum number of neighbours"); return ET_E_INSUFFICIENT_PEERS; }
     if (parts.size() > 0xFFFFFFF0u) return ET_E_UNSUPPORTED;
@@ -443,16 +484,18 @@ int et_scores_from_attestations(const et_attestation* atts, size_t n_att, const 
     auto index_of = [&](const uint8_t* a) -> uint32_t {
         Addr key;
         std::memcpy(key.data(), a, 20);
-        return (uint32_t)(std::lower_bound(parts.begin(), parts.end(), key) - parts.begin());
+        return (uint32_t)(std::lower_bound(parts.begin() + uniq[a[0]], parts.begin() + uniq[a[0] + 1], key) - parts.begin());
     };
     // one edge per record, in record order: a later record of the same (attester, about) pair replaces an
     // earlier one (lib.rs:404-419); self-attestations and zero values drop out in the filter (native.rs:248-260)
     std::vector<uint32_t> from(n_att), to(n_att), val(n_att);
-    for (size_t k = 0; k < n_att; ++k) {
-        from[k] = index_of(who.data() + 20 * k);
-        to[k] = index_of(atts[k].about);
-        val[k] = atts[k].value;
-    }
+    run_threads(T, [&](unsigned t) {
+        for (size_t k = n_att * t / T; k < n_att * (t + 1) / T; ++k) {
+            from[k] = index_of(who.data() + 20 * k);
+            to[k] = index_of(atts[k].about);
+            val[k] = atts[k].value;
+        }
+    });
     et_build_opts opts;
     std::memset(&opts, 0, sizeof opts);
     opts.n_seg = 1;

@@ -302,12 +302,15 @@ def scores_from_attestations(attestations, domain=bytes(20), num_iterations=20, 
     count = C.c_size_t(0)
     dom = _addr(domain)
     head = (arr, n, dom, num_iterations, initial_score & (2**64 - 1), initial_score >> 64)
-    check(lib().et_scores_from_attestations(*head, None, None, None, 0, C.byref(count)))
+    # one call (a size query would recover every signature a second time): at most 2 participants per record
+    cap = max(2, 2 * n)
+    addrs = (C.c_uint8 * (20 * cap))()
+    fr = np.zeros((cap, 32), dtype=np.uint8)
+    d64 = np.zeros(cap, dtype=np.float64) if f64 else None
+    check(lib().et_scores_from_attestations(*head, addrs, fr.ctypes.data, d64.ctypes.data if f64 else None, cap, C.byref(count)))
     m = count.value
-    addrs = (C.c_uint8 * (20 * m))()
-    fr = np.zeros((m, 32), dtype=np.uint8)
-    d64 = np.zeros(m, dtype=np.float64) if f64 else None
-    check(lib().et_scores_from_attestations(*head, addrs, fr.ctypes.data, d64.ctypes.data if f64 else None, m, C.byref(count)))
+    fr = fr[:m]
+    d64 = d64[:m] if f64 else None
     out_addr = [bytes(addrs[20 * i:20 * i + 20]) for i in range(m)]
     ints = [int.from_bytes(fr[i].tobytes(), "little") for i in range(m)]
     return (out_addr, ints, d64) if f64 else (out_addr, ints)
