@@ -255,9 +255,9 @@ int et_graph_result_f64(et_graph *g, double *out, void *stream);
 /* ------------------------------------------------------------------------------------------
  * Batches of small independent sets (ZK witness generation): n_sets sets of n <= 1024 slots.
  * One workgroup per set runs the whole converge in a single launch; sets never communicate, so a
- * batch is split over GPUs by creating one sub-batch per GPU.  Sets of up to 256 slots whose opinions
- * fit a byte (the production range, eigentrust/src/attestation.rs:304) run their dense product on the
- * matrix cores; larger sets and larger opinions run on the vector ALUs.  Results are bit-exact either way.
+ * batch is split over GPUs by creating one sub-batch per GPU.  Sets whose opinions fit a byte (the
+ * production range, eigentrust/src/attestation.rs:304) run their dense product on the matrix cores;
+ * larger opinions run on the vector ALUs.  Results are bit-exact either way.
  *   member : n_sets*n flags or NULL (every slot holds a peer)
  *   values : n_sets*n*n opinions, values[s][i][j] = what Opinion::validate returns for attester i
  *            about slot j (opinion/native.rs:63-109), as small integers

@@ -394,6 +394,44 @@ struct BatchArgsM {
     U256 initial_m;          // INITIAL_SCORE * 2^256 mod r
 };
 
+// The two 32 x 32 result tiles of a wavefront (limb rows x columns), the tile against the matrix of ones and the
+// per-column constants, turned into ONE column sum per lane.  Register q of a lane is limb
+// (q & 3) + 8 * (q >> 2) + 4 * h of its column (h = lane half): registers 4g..4g+3 are the four bytes of 32-bit
+// word 2g + h.  Lane half 0 keeps tile 0, lane half 1 keeps tile 1; the words of the other tile are swapped
+// with lane ^ 32.
+ET_DEV Acc10 mfma_tiles_to_column(const v16i& acc0, const v16i& acc1, const v16i& acc2, int kc0, int kc1, int h) {
+    uint64_t keep[4], give[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint64_t t0 = 0, t1 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m1 = 128 * acc2[4 * g + q];
+            t0 += (uint64_t)(uint32_t)(acc0[4 * g + q] + m1 + kc0) << (8 * q);
+            t1 += (uint64_t)(uint32_t)(acc1[4 * g + q] + m1 + kc1) << (8 * q);
+        }
+        keep[g] = h ? t1 : t0;
+        give[g] = h ? t0 : t1;
+    }
+    Acc10 acc;
+    uint64_t c = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t lo = __shfl_xor((uint32_t)give[g], 32, 64), hi = __shfl_xor((uint32_t)(give[g] >> 32), 32, 64);
+        const uint64_t got = ((uint64_t)hi << 32) | lo;
+        const uint64_t even = h ? got : keep[g], odd = h ? keep[g] : got;
+        c += even;
+        acc.v[2 * g] = (uint32_t)c;
+        c >>= 32;
+        c += odd;
+        acc.v[2 * g + 1] = (uint32_t)c;
+        c >>= 32;
+    }
+    acc.v[8] = (uint32_t)c;
+    acc.v[9] = (uint32_t)(c >> 32);
+    return acc;
+}
+
 static const uint32_t MFMA_ROW_PAD = 16;   // bytes between limb rows of xs in LDS: spreads the 16-byte operand reads over the banks
 
 template <int KS>   // np / 32
@@ -449,38 +487,7 @@ __global__ __launch_bounds__(KS * 32) __attribute__((amdgpu_waves_per_eu(3, 3)))
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, b1[ks], acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, ones, acc2, 0, 0, 0);
         }
-        // Register q of a lane is limb (q & 3) + 8 * (q >> 2) + 4 * h of its column: registers 4g..4g+3 are the
-        // four bytes of 32-bit word 2g + h.  Lane half 0 keeps tile 0, lane half 1 keeps tile 1; the words
-        // of the other tile are swapped with lane ^ 32.
-        uint64_t keep[4], give[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint64_t t0 = 0, t1 = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m1 = 128 * acc2[4 * g + q];
-                t0 += (uint64_t)(uint32_t)(acc0[4 * g + q] + m1 + kc0) << (8 * q);
-                t1 += (uint64_t)(uint32_t)(acc1[4 * g + q] + m1 + kc1) << (8 * q);
-            }
-            keep[g] = h ? t1 : t0;
-            give[g] = h ? t0 : t1;
-        }
-        Acc10 acc;
-        uint64_t c = 0;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const uint32_t lo = __shfl_xor((uint32_t)give[g], 32, 64), hi = __shfl_xor((uint32_t)(give[g] >> 32), 32, 64);
-            const uint64_t got = ((uint64_t)hi << 32) | lo;
-            const uint64_t even = h ? got : keep[g], odd = h ? keep[g] : got;
-            c += even;
-            acc.v[2 * g] = (uint32_t)c;
-            c >>= 32;
-            c += odd;
-            acc.v[2 * g + 1] = (uint32_t)c;
-            c >>= 32;
-        }
-        acc.v[8] = (uint32_t)c;
-        acc.v[9] = (uint32_t)(c >> 32);
+        const Acc10 acc = mfma_tiles_to_column(acc0, acc1, acc2, kc0, kc1, h);
         if (it + 1 == a.num_iter) s = is_member ? acc_redc288(acc_from_acc10(acc)) : u256_zero();
         else sm = is_member ? acc_redc_loose<1>(acc_from_acc10(acc)) : u256_zero();
     }
@@ -502,6 +509,79 @@ __global__ __launch_bounds__(KS * 32) __attribute__((amdgpu_waves_per_eu(3, 3)))
         U256 t = u256_zero();
         uint32_t members = 0;
         for (int w = 0; w < KS / 2; ++w) { t = fr_add(t, u256_load(red_l + 2 * w)); members += sh_nv[w]; }
+        U256 expect = u256_zero();
+        for (uint32_t k = 0; k < members; ++k) expect = fr_add(expect, a.initial);
+        a.status[set] = u256_eq(t, expect) ? ET_OK : ET_E_SUM_MISMATCH;
+    }
+}
+
+// The same for sets of up to 1024 slots, whose opinion bytes do not fit the registers of their wavefronts:
+// every k-step's two operands are read again from the transposed matrix in global memory (a set's matrix is
+// at most 1 MiB and stays in the caches over its 20 iterations); LDS holds the two copies of xs only.
+__global__ __launch_bounds__(1024) void k_batch_fr_mfma_stream(BatchArgsM am) {
+    const BatchArgs& a = am.b;
+    extern __shared__ __attribute__((aligned(16))) uint8_t xsb_dyn[];
+    __shared__ uint4 red_l[2 * 16];
+    __shared__ uint32_t sh_nv[16];
+    const uint32_t NP = am.np, ROW = NP + MFMA_ROW_PAD, KS = NP / 32;
+    const uint32_t n = a.n, set = blockIdx.x, e = threadIdx.x;
+    const int lane = e & 63, wave = e >> 6, r = lane & 31, h = lane >> 5, n_waves = NP / 64;
+    uint4* outp = a.out + 2 * (size_t)set * n;
+    if (a.pre_status[set] != ET_OK) {
+        if (e < n) u256_store(outp + 2 * e, u256_zero());
+        if (e == 0) a.status[set] = a.pre_status[set];
+        return;
+    }
+    const uint8_t* vt = reinterpret_cast<const uint8_t*>(a.vals) + (size_t)set * NP * NP;
+    const uint8_t* __restrict__ p0 = vt + (size_t)(wave * 64 + r) * NP + 16 * h;
+    const uint8_t* __restrict__ p1 = p0 + (size_t)32 * NP;
+    const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
+    const int kc0 = (int)(128u * am.colsum[(size_t)set * NP + wave * 64 + r]);
+    const int kc1 = (int)(128u * am.colsum[(size_t)set * NP + wave * 64 + 32 + r]);
+    const bool is_member = e < n && a.member[(size_t)set * n + e] != 0;
+    const U256 scale = is_member ? u256_load(a.scale + 2 * ((size_t)set * n + e)) : u256_zero();
+    U256 s = is_member ? a.initial : u256_zero();
+    U256 sm = is_member ? am.initial_m : u256_zero();
+
+    for (uint32_t it = 0; it < a.num_iter; ++it) {
+        uint8_t* xb = xsb_dyn + (size_t)(it & 1) * 32 * ROW;
+        Acc prod = acc_zero();
+        acc_mac(prod, sm, scale);
+        const U256 xs = acc_redc_loose<8>(prod);
+#pragma unroll
+        for (int l = 0; l < 32; ++l) xb[l * ROW + e] = (uint8_t)(((xs.v[l >> 2] >> (8 * (l & 3))) & 0xFFu) ^ 0x80u);
+        __syncthreads();
+        v16i acc0 = {0}, acc1 = {0}, acc2 = {0};
+        const uint8_t* xrow = xb + r * ROW + 16 * h;
+        for (uint32_t ks = 0; ks < KS; ++ks) {
+            const v4i x = *reinterpret_cast<const v4i*>(xrow + ks * 32);
+            const v4i b0 = *reinterpret_cast<const v4i*>(p0 + ks * 32);
+            const v4i b1 = *reinterpret_cast<const v4i*>(p1 + ks * 32);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, b1, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, ones, acc2, 0, 0, 0);
+        }
+        const Acc10 acc = mfma_tiles_to_column(acc0, acc1, acc2, kc0, kc1, h);
+        if (it + 1 == a.num_iter) s = is_member ? acc_redc288(acc_from_acc10(acc)) : u256_zero();
+        else sm = is_member ? acc_redc_loose<1>(acc_from_acc10(acc)) : u256_zero();
+    }
+    if (e < n) u256_store(outp + 2 * e, s);
+    U256 tot = s;
+    uint32_t nv = is_member;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        U256 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o.v[q] = __shfl_xor(tot.v[q], off, 64);
+        tot = fr_add(tot, o);
+        nv += __shfl_xor(nv, off, 64);
+    }
+    if (lane == 0) { u256_store(red_l + 2 * wave, tot); sh_nv[wave] = nv; }
+    __syncthreads();
+    if (e == 0) {
+        U256 t = u256_zero();
+        uint32_t members = 0;
+        for (int w = 0; w < n_waves; ++w) { t = fr_add(t, u256_load(red_l + 2 * w)); members += sh_nv[w]; }
         U256 expect = u256_zero();
         for (uint32_t k = 0; k < members; ++k) expect = fr_add(expect, a.initial);
         a.status[set] = u256_eq(t, expect) ? ET_OK : ET_E_SUM_MISMATCH;
@@ -616,7 +696,7 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
     const size_t cells = rows * n;
     b.vals_u8 = vmax.load() <= 255;
     const char* no_mfma = getenv("ET_BATCH_NO_MFMA");   // measurement knob: the VALU kernel for small byte sets too
-    b.mfma = b.vals_u8 && n <= 256 && !(no_mfma && no_mfma[0] == '1');
+    b.mfma = b.vals_u8 && !(no_mfma && no_mfma[0] == '1');   // n <= 1024 was checked above
     if (b.mfma) {
         // [column i][source j] bytes of v_ji - 128, padded to np x np with v = 0; a peer without valid
         // opinions becomes a row of ones over the other members with factor inv(n_valid - 1) (native.rs:263-278)
@@ -716,7 +796,12 @@ int et_batch_run_fr_async(et_batch* h, uint32_t num_iterations, uint64_t initial
             case 1: hipLaunchKernelGGL((k_batch_fr_mfma<2>), dim3(b.n_sets), dim3(64), 0, st, am); break;
             case 2: hipLaunchKernelGGL((k_batch_fr_mfma<4>), dim3(b.n_sets), dim3(128), 0, st, am); break;
             case 3: hipLaunchKernelGGL((k_batch_fr_mfma<6>), dim3(b.n_sets), dim3(192), 0, st, am); break;
-            default: hipLaunchKernelGGL((k_batch_fr_mfma<8>), dim3(b.n_sets), dim3(256), 0, st, am); break;
+            case 4: hipLaunchKernelGGL((k_batch_fr_mfma<8>), dim3(b.n_sets), dim3(256), 0, st, am); break;
+            default: {
+                const size_t lds = (size_t)2 * 32 * (b.np + MFMA_ROW_PAD);
+                HIP_TRY_B(hipFuncSetAttribute((const void*)k_batch_fr_mfma_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_batch_fr_mfma_stream, dim3(b.n_sets), dim3(b.np), lds, st, am);
+            }
         }
     } else if (b.vals_u8) {
         BatchArgsU8 au;

@@ -17,22 +17,23 @@ def dense_expect(values, member, iters, initial):
 
 @pytest.mark.parametrize("n,n_sets,vmax", [(4, 9, 255), (12, 5, 1000), (64, 6, 255), (256, 8, 255), (256, 3, 2**32 - 1),
                                           (300, 2, 255), (700, 1, 70000),
-                                          # byte opinions: every tile count of the matrix-core kernel (n <= 256), then the
-                                          # vector kernel with the matrix in LDS / left in global memory, >256 sources per part
+                                          # byte opinions: every tile count of the matrix-core kernel with resident operands
+                                          # (n <= 256), then the one that streams them (n <= 1024)
                                           (33, 4, 3), (100, 3, 255), (130, 2, 200), (192, 2, 255), (200, 2, 255),
                                           (400, 2, 255), (1000, 1, 255)])
 def test_batch_matches_dense_restatement(n, n_sets, vmax):
     _check_batch(n, n_sets, vmax)
 
 
-@pytest.mark.parametrize("n,n_sets,vmax", [(33, 4, 3), (130, 2, 200), (256, 2, 255)])
+@pytest.mark.parametrize("n,n_sets,vmax", [(33, 4, 3), (130, 2, 200), (256, 2, 255), (400, 2, 255), (1000, 1, 255)])
 def test_batch_vector_kernel_on_small_byte_sets(n, n_sets, vmax, monkeypatch):
-    # uneven column split of the byte-valued vector kernel, which small sets reach only with the matrix cores switched off
+    # the byte-valued vector kernel (uneven column split, matrix in LDS / left in global memory, >256 sources per
+    # part), which byte sets reach only with the matrix cores switched off
     monkeypatch.setenv("ET_BATCH_NO_MFMA", "1")
     _check_batch(n, n_sets, vmax)
 
 
-@pytest.mark.parametrize("n,iters", [(256, 20), (200, 20), (64, 1), (64, 0), (5, 3)])
+@pytest.mark.parametrize("n,iters", [(256, 20), (200, 20), (64, 1), (64, 0), (5, 3), (512, 20), (1024, 3), (700, 0)])
 def test_batch_extreme_bytes(n, iters):
     # the largest column sums the byte-limb product can see (every opinion 255), and a 0/255 mix
     rng = np.random.default_rng(n + iters)
