@@ -1,8 +1,11 @@
 // Batches of small independent sets (ZK witness generation: thousands of 256-peer sets).
 //
 // One workgroup per set; the whole converge of a set (dynamic_sets/native.rs:286-337) runs in ONE
-// launch: the trust vector lives in LDS for all iterations and, when the opinions fit a byte (the
-// production range, eigentrust/src/attestation.rs:304), so does the set's opinion matrix.
+// launch.  Opinions that fit a byte (the production range, eigentrust/src/attestation.rs:304): the
+// dense product runs on the matrix cores as a product of byte limbs (k_batch_fr_mfma for sets of
+// up to 256 slots, k_batch_fr_mfma_stream up to 1024).  Larger opinions: k_batch_fr on the vector
+// ALUs with the trust vector in LDS; k_batch_fr_u8 is the byte-valued vector-ALU kernel the
+// matrix-core ones are measured against.
 // Sets never communicate, so a batch is split over GPUs by giving each its own sub-batch.
 //
 // The dense row of ones of a peer without valid opinions (native.rs:263-278) is evaluated as the
