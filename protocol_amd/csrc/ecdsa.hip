@@ -54,8 +54,17 @@ struct RecoverConsts {
     ModConst mod[3];
     F256 gx, gy;          // generator, plain form mod p
     F256 seven;           // 7
-    F256 rc[340];         // Poseidon round constants, Montgomery form mod r
+    // Poseidon 5x5 (poseidon/native/mod.rs:34-97), Montgomery form mod r, with the 60 partial rounds in their
+    // sparse form: the matrix of a partial round factors into a sparse one (first row, first column, identity)
+    // times one that leaves element 0 alone and therefore commutes with the partial S-box; pushing those
+    // factors back to the last full round before them leaves 9 instead of 25 multiplications per partial round.
+    F256 rc_full[8 * 5];      // constants of the 8 full rounds; those of the first round after the partial ones include what the partial rounds carried forward
     F256 mds[25];
+    F256 mds_pre[25];         // matrix of the last full round before the partial rounds
+    F256 rc_first[5];         // added to all five elements before the first partial round
+    F256 rc0[60];             // added to element 0 before the S-box of partial round k (k >= 1)
+    F256 sp_row[60 * 5];      // first row of the sparse matrix of partial round k
+    F256 sp_col[60 * 4];      // its first column below the corner
 };
 
 #define EC_DEV __host__ __device__ __forceinline__
@@ -92,6 +101,24 @@ EC_DEV F256 f_sub_raw(const F256& a, const uint32_t* m) {
     }
     return r;
 }
+// a - m when `force` is set or a >= m, else a: difference and borrow in one pass, limbs chosen without a branch.
+// (The form `if (a >= m) a = a - m;` on the whole struct came out wrong from the device compiler at -O2 and -O3 in
+// some inlining contexts: sums off by the modulus' low limb.  Every reduction here selects limb by limb instead.)
+EC_DEV F256 f_cond_sub(const F256& a, const uint32_t* m, bool force) {
+    F256 d;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t t = (uint64_t)a.v[i] - m[i] - br;
+        d.v[i] = (uint32_t)t;
+        br = (t >> 32) & 1;
+    }
+    const bool take = force || br == 0;
+    F256 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = take ? d.v[i] : a.v[i];
+    return r;
+}
 EC_DEV F256 f_add(const F256& a, const F256& b, const ModConst& M) {
     F256 r;
     uint64_t c = 0;
@@ -101,26 +128,25 @@ EC_DEV F256 f_add(const F256& a, const F256& b, const ModConst& M) {
         r.v[i] = (uint32_t)t;
         c = t >> 32;
     }
-    if (c || f_geq(r, M.m)) r = f_sub_raw(r, M.m);
-    return r;
+    return f_cond_sub(r, M.m, c != 0);
 }
 EC_DEV F256 f_sub(const F256& a, const F256& b, const ModConst& M) {
-    F256 r;
+    F256 d;
     uint64_t br = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        uint64_t d = (uint64_t)a.v[i] - b.v[i] - br;
-        r.v[i] = (uint32_t)d;
-        br = (d >> 32) & 1;
+        uint64_t t = (uint64_t)a.v[i] - b.v[i] - br;
+        d.v[i] = (uint32_t)t;
+        br = (t >> 32) & 1;
     }
-    if (br) {
-        uint64_t c = 0;
+    // a < b: add the modulus back (selected per limb, no branch)
+    F256 r;
+    uint64_t c = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            uint64_t t = (uint64_t)r.v[i] + M.m[i] + c;
-            r.v[i] = (uint32_t)t;
-            c = t >> 32;
-        }
+    for (int i = 0; i < 8; ++i) {
+        uint64_t t = (uint64_t)d.v[i] + (br ? M.m[i] : 0u) + c;
+        r.v[i] = (uint32_t)t;
+        c = t >> 32;
     }
     return r;
 }
@@ -157,8 +183,7 @@ EC_DEV F256 f_mul(const F256& a, const F256& b, const ModConst& M) {
     F256 r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.v[i] = t[i];
-    if (t[8] || f_geq(r, M.m)) r = f_sub_raw(r, M.m);
-    return r;
+    return f_cond_sub(r, M.m, t[8] != 0);
 }
 // sum_{k<5} a[k] * b[k] * 2^-256 mod m: the five products are added unreduced (5 m^2 < 2^515 fits 17 limbs)
 // and reduced once -- one Montgomery reduction per row of the Poseidon matrix instead of five
@@ -201,24 +226,12 @@ EC_DEV F256 f_dot5(const F256* a, const F256* b, const ModConst& M) {
         t[i + 8] = (uint32_t)v;
         carry = (uint32_t)(v >> 32);
     }
-    // the quotient is below 5 m^2 / 2^256 + m < 3 m for the moduli here (m < 2^254) and fits nine limbs
+    // (5 m^2 + 2^256 m) / 2^256 < 2 m < 2^256 for a modulus below 0.2 * 2^256 (the bn256 scalar field, the only
+    // one this is used with): the quotient fits eight limbs and one subtraction brings it below m
     F256 r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.v[i] = t[8 + i];
-    uint32_t hi = t[16] + carry;
-    for (int k = 0; k < 3; ++k) {
-        if (hi || f_geq(r, M.m)) {
-            uint64_t br = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                uint64_t d = (uint64_t)r.v[i] - M.m[i] - br;
-                r.v[i] = (uint32_t)d;
-                br = (d >> 32) & 1;
-            }
-            hi -= (uint32_t)br;
-        }
-    }
-    return r;
+    return f_cond_sub(r, M.m, false);
 }
 EC_DEV F256 f_load_mod(const uint32_t* p) {
     F256 r;
@@ -291,8 +304,7 @@ EC_DEV F256 fp_reduce512(const uint32_t* t, const ModConst& P) {
     F256 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o.v[i] = r[i];
-    if (f_geq(o, P.m)) o = f_sub_raw(o, P.m);
-    return o;
+    return f_cond_sub(o, P.m, false);
 }
 EC_DEV F256 fp_mul(const F256& a, const F256& b, const ModConst& P) {
     uint32_t t[16];
@@ -478,26 +490,39 @@ EC_DEV void recover_lane(const uint8_t* rec, const RecoverConsts* K, const F256*
         value.v[0] = rec[40];
         for (int b = 0; b < 32; ++b) message.v[b >> 2] |= (uint32_t)rec[41 + 31 - b] << (8 * (b & 3));
         // the message is a 256-bit big-endian integer reduced mod r (attestation.rs:107-113): at most five subtractions
-        for (int k = 0; k < 6; ++k) if (f_geq(message, R.m)) message = f_sub_raw(message, R.m);
+        for (int k = 0; k < 6; ++k) message = f_cond_sub(message, R.m, false);
         st[0] = f_to_mont(about, R); st[1] = f_to_mont(domain, R); st[2] = f_to_mont(value, R); st[3] = f_to_mont(message, R);
 #pragma unroll
         for (int k = 0; k < 8; ++k) st[4].v[k] = 0;
     }
-    for (int round = 0; round < 68; ++round) {   // poseidon/native/mod.rs:34-97: 4 full, 60 partial, 4 full
-        const bool full = round < 4 || round >= 64;
+    for (int half = 0; half < 2; ++half) {       // 4 full rounds, 60 partial rounds, 4 full rounds
+        for (int fr = 0; fr < 4; ++fr) {
+            const int round = half * 4 + fr;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) st[k] = f_add(st[k], K->rc[round * 5 + k], R);
-        if (full) {
+            for (int k = 0; k < 5; ++k) {
+                st[k] = f_add(st[k], K->rc_full[round * 5 + k], R);
+                F256 x2 = f_mul(st[k], st[k], R);
+                st[k] = f_mul(f_mul(x2, x2, R), st[k], R);
+            }
+            const F256* m = round == 3 ? K->mds_pre : K->mds;
+            F256 o[5];
+            for (int a = 0; a < 5; ++a) o[a] = f_dot5(m + a * 5, st, R);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) { F256 x2 = f_mul(st[k], st[k], R); st[k] = f_mul(f_mul(x2, x2, R), st[k], R); }
-        } else {
-            F256 x2 = f_mul(st[0], st[0], R);
-            st[0] = f_mul(f_mul(x2, x2, R), st[0], R);
+            for (int k = 0; k < 5; ++k) st[k] = o[k];
         }
-        F256 o[5];
-        for (int a = 0; a < 5; ++a) o[a] = f_dot5(K->mds + a * 5, st, R);
+        if (half == 0) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) st[k] = o[k];
+            for (int k = 0; k < 5; ++k) st[k] = f_add(st[k], K->rc_first[k], R);
+            for (int pr = 0; pr < 60; ++pr) {
+                if (pr) st[0] = f_add(st[0], K->rc0[pr], R);
+                F256 x2 = f_mul(st[0], st[0], R);
+                st[0] = f_mul(f_mul(x2, x2, R), st[0], R);
+                const F256 head = f_dot5(K->sp_row + pr * 5, st, R);
+#pragma unroll
+                for (int k = 1; k < 5; ++k) st[k] = f_add(st[k], f_mul(K->sp_col[pr * 4 + k - 1], st[0], R), R);
+                st[0] = head;
+            }
+        }
     }
     F256 hash = f_from_mont(st[0], R);   // < r < n: usable as a secp256k1 scalar as it is (attestation.rs:225-233)
 
@@ -604,11 +629,107 @@ static int build_consts(RecoverConsts& K) {
     put(K.gx.v, SECP_GX);
     put(K.gy.v, SECP_GY);
     put(K.seven.v, U256h{{7, 0, 0, 0}});
-    std::vector<FrRaw> rc, mds;
-    poseidon5_parameters(rc, mds);
-    if (rc.size() != 340 || mds.size() != 25) { set_error("internal: Poseidon parameter count"); return ET_E_UNSUPPORTED; }
-    for (size_t i = 0; i < 340; ++i) { U256h v; std::memcpy(v.l, rc[i].l, 32); put(K.rc[i].v, MR.to(v)); }
-    for (size_t i = 0; i < 25; ++i) { U256h v; std::memcpy(v.l, mds[i].l, 32); put(K.mds[i].v, MR.to(v)); }
+    std::vector<FrRaw> rc_raw, mds_raw;
+    poseidon5_parameters(rc_raw, mds_raw);
+    if (rc_raw.size() != 340 || mds_raw.size() != 25) { set_error("internal: Poseidon parameter count"); return ET_E_UNSUPPORTED; }
+    auto store = [&](F256& dst, const Fr& v) { const FrRaw raw = v.to_raw(); U256h u; std::memcpy(u.l, raw.l, 32); put(dst.v, MR.to(u)); };
+    typedef std::vector<std::vector<Fr>> Mat;
+    Mat M(5, std::vector<Fr>(5));
+    for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) M[i][j] = Fr::from_raw(mds_raw[i * 5 + j]);
+    std::vector<std::vector<Fr>> RC(68, std::vector<Fr>(5));
+    for (int k = 0; k < 68; ++k) for (int i = 0; i < 5; ++i) RC[k][i] = Fr::from_raw(rc_raw[k * 5 + i]);
+    auto matmul = [](const Mat& A, const Mat& B) {
+        Mat C(A.size(), std::vector<Fr>(B[0].size()));
+        for (size_t i = 0; i < A.size(); ++i) for (size_t j = 0; j < B[0].size(); ++j) {
+            Fr acc = Fr::zero();
+            for (size_t k = 0; k < B.size(); ++k) acc += A[i][k] * B[k][j];
+            C[i][j] = acc;
+        }
+        return C;
+    };
+    auto matvec = [](const Mat& A, const std::vector<Fr>& v) {
+        std::vector<Fr> o(A.size());
+        for (size_t i = 0; i < A.size(); ++i) { Fr acc = Fr::zero(); for (size_t j = 0; j < v.size(); ++j) acc += A[i][j] * v[j]; o[i] = acc; }
+        return o;
+    };
+    auto invert4 = [](Mat a, bool& ok) {      // Gauss-Jordan on the 4 x 4 block
+        const int n = 4;
+        Mat inv(n, std::vector<Fr>(n, Fr::zero()));
+        for (int i = 0; i < n; ++i) inv[i][i] = Fr::one();
+        for (int col = 0; col < n; ++col) {
+            int p = col;
+            while (p < n && a[p][col].is_zero()) ++p;
+            if (p == n) { ok = false; return inv; }
+            std::swap(a[p], a[col]);
+            std::swap(inv[p], inv[col]);
+            const Fr iv = a[col][col].invert_or_zero();
+            for (int j = 0; j < n; ++j) { a[col][j] *= iv; inv[col][j] *= iv; }
+            for (int r = 0; r < n; ++r) {
+                if (r == col || a[r][col].is_zero()) continue;
+                const Fr f = a[r][col];
+                for (int j = 0; j < n; ++j) { a[r][j] = a[r][j] - f * a[col][j]; inv[r][j] = inv[r][j] - f * inv[col][j]; }
+            }
+        }
+        return inv;
+    };
+    // backward over the partial rounds: M_k = S_k * P_k with S_k sparse and P_k = diag(1, lower block of M_k);
+    // P_k moves in front of the S-box of its round and joins the matrix of the round before: M_{k-1} = P_k * M
+    std::vector<std::vector<Fr>> sp_row(60), sp_col(60);
+    std::vector<Mat> P(60);
+    Mat cur = M;
+    for (int k = 59; k >= 0; --k) {
+        Mat low(4, std::vector<Fr>(4));
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) low[i][j] = cur[i + 1][j + 1];
+        bool ok = true;
+        const Mat low_inv = invert4(low, ok);
+        if (!ok) { set_error("internal: singular block in the Poseidon matrix"); return ET_E_UNSUPPORTED; }
+        sp_row[k].assign(5, Fr::zero());
+        sp_col[k].assign(4, Fr::zero());
+        sp_row[k][0] = cur[0][0];
+        for (int j = 0; j < 4; ++j) {
+            Fr acc = Fr::zero();
+            for (int i = 0; i < 4; ++i) acc += cur[0][i + 1] * low_inv[i][j];
+            sp_row[k][j + 1] = acc;
+            sp_col[k][j] = cur[j + 1][0];
+        }
+        Mat Pk(5, std::vector<Fr>(5, Fr::zero()));
+        Pk[0][0] = Fr::one();
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Pk[i + 1][j + 1] = low[i][j];
+        P[k] = Pk;
+        cur = matmul(Pk, M);
+    }
+    auto sparse_apply = [&](int k, const std::vector<Fr>& z) {
+        std::vector<Fr> o(5);
+        Fr acc = Fr::zero();
+        for (int j = 0; j < 5; ++j) acc += sp_row[k][j] * z[j];
+        o[0] = acc;
+        for (int i = 1; i < 5; ++i) o[i] = sp_col[k][i - 1] * z[0] + z[i];
+        return o;
+    };
+    // constants: P_k * c_k; only element 0 of it sits before the S-box, the rest rides through the sparse matrix
+    // into the next round's constant, and what is left after the last partial round joins the next full round
+    std::vector<Fr> carry(5, Fr::zero());
+    const std::vector<Fr> first = matvec(P[0], RC[4]);
+    for (int i = 0; i < 5; ++i) store(K.rc_first[i], first[i]);
+    store(K.rc0[0], Fr::zero());
+    for (int k = 1; k < 60; ++k) {
+        std::vector<Fr> eff = matvec(P[k], RC[4 + k]);
+        for (int i = 0; i < 5; ++i) eff[i] += carry[i];
+        store(K.rc0[k], eff[0]);
+        eff[0] = Fr::zero();
+        carry = sparse_apply(k, eff);
+    }
+    for (int round = 0; round < 8; ++round)
+        for (int i = 0; i < 5; ++i) {
+            Fr c = RC[round < 4 ? round : 60 + round][i];
+            if (round == 4) c += carry[i];
+            store(K.rc_full[round * 5 + i], c);
+        }
+    for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) { store(K.mds[i * 5 + j], M[i][j]); store(K.mds_pre[i * 5 + j], cur[i][j]); }
+    for (int k = 0; k < 60; ++k) {
+        for (int j = 0; j < 5; ++j) store(K.sp_row[k * 5 + j], sp_row[k][j]);
+        for (int j = 0; j < 4; ++j) store(K.sp_col[k * 4 + j], sp_col[k][j]);
+    }
     return ET_OK;
 }
 
