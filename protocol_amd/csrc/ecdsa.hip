@@ -733,6 +733,16 @@ static int build_consts(RecoverConsts& K) {
     return ET_OK;
 }
 
+// The constants are derived once per process (the sparse Poseidon matrices cost a few milliseconds).
+static int recover_consts(const RecoverConsts** out) {
+    static std::vector<RecoverConsts> cached(1);
+    static int status = ET_OK;
+    static std::once_flag once;
+    std::call_once(once, [&]() { status = build_consts(cached[0]); });
+    *out = &cached[0];
+    return status;
+}
+
 // Fixed-base table for the generator: entry [w][d] = d * 2^(8w) * G in affine plain coordinates (x, y), d = 1..255
 // (entry 0 unused), 32 windows: u1 * G is the sum of one entry per byte of u1.  Built once per process with the
 // lane arithmetic itself; the Jacobian results are brought to affine form with one shared inversion.
@@ -791,10 +801,10 @@ extern "C" int et_attestations_recover_gpu(const et_attestation* atts, size_t n,
     HIP_TRY_E(hipSetDevice(device));
     if (n == 0) return ET_OK;
 
-    std::vector<RecoverConsts> kc(1);
-    RecoverConsts& K = kc[0];
-    int rcc = build_consts(K);
+    const RecoverConsts* kp = nullptr;
+    int rcc = recover_consts(&kp);
     if (rcc) return rcc;
+    const RecoverConsts& K = *kp;
 
     uint8_t *d_recs = nullptr, *d_addr = nullptr, *d_keys = nullptr, *d_status = nullptr;
     RecoverConsts* d_k = nullptr;
@@ -834,12 +844,12 @@ extern "C" int et_attestations_recover_gpu(const et_attestation* atts, size_t n,
 // checked where no GPU is present.  A self-test hook, not a compute path.
 extern "C" int et_attestation_recover_lane_host(const et_attestation* att, uint8_t attester[20], uint8_t public_key[64]) {
     if (!att || !attester || !public_key) return ET_E_INVALID_ARG;
-    std::vector<RecoverConsts> kc(1);
-    int rc = build_consts(kc[0]);
+    const RecoverConsts* kp = nullptr;
+    int rc = recover_consts(&kp);
     if (rc) return rc;
     uint8_t status = 0;
     uint32_t key[16];
-    recover_lane(reinterpret_cast<const uint8_t*>(att), &kc[0], generator_table(kc[0]).data(), attester, key, &status);
+    recover_lane(reinterpret_cast<const uint8_t*>(att), kp, generator_table(*kp).data(), attester, key, &status);
     std::memcpy(public_key, key, 64);
     if (status != REC_OK) { set_error("lane status " + std::to_string((int)status)); return ET_E_BAD_SIGNATURE; }
     return ET_OK;
