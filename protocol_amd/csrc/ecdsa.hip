@@ -54,6 +54,10 @@ struct RecoverConsts {
     ModConst mod[3];
     F256 gx, gy;          // generator, plain form mod p
     F256 seven;           // 7
+    // the curve's endomorphism (x, y) -> (beta * x, y) = lambda * (x, y): a scalar k splits into k1 + k2 * lambda
+    // with |k1|, |k2| < 2^128 (lattice basis (a1, b1), (a2, b2) of {(x, y): x + y * lambda = 0 mod n}, nb1 = -b1,
+    // g1 = round(2^384 * b2 / n), g2 = round(2^384 * nb1 / n)), which halves the doublings of a scalar multiplication
+    F256 beta, g1, g2, a1, a2, nb1, b2;
     // Poseidon 5x5 (poseidon/native/mod.rs:34-97), Montgomery form mod r, with the 60 partial rounds in their
     // sparse form: the matrix of a partial round factors into a sparse one (first row, first column, identity)
     // times one that leaves element 0 alone and therefore commutes with the partial S-box; pushing those
@@ -435,6 +439,74 @@ EC_DEV JPt j_add_affine(const JPt& p, const F256& qx, const F256& qy, const ModC
     return o;
 }
 
+// ---- plain 256-bit helpers for the scalar split --------------------------------------------------------
+EC_DEV F256 u256_mul_lo(const F256& a, const F256& b) {          // a * b mod 2^256
+    uint32_t t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j + i < 8; ++j) {
+            uint64_t v = (uint64_t)a.v[j] * b.v[i] + t[i + j] + c;
+            t[i + j] = (uint32_t)v;
+            c = v >> 32;
+        }
+    }
+    F256 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = t[i];
+    return r;
+}
+EC_DEV F256 u256_mul_shift384(const F256& k, const F256& g) {    // round(k * g / 2^384), below 2^128
+    uint32_t t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t v = (uint64_t)k.v[j] * g.v[i] + t[i + j] + c;
+            t[i + j] = (uint32_t)v;
+            c = v >> 32;
+        }
+        t[i + 8] = (uint32_t)c;
+    }
+    uint64_t c = (uint64_t)t[11] + 0x80000000u;                    // + 2^383
+    c >>= 32;
+    F256 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { uint64_t v = (uint64_t)t[12 + i] + c; r.v[i] = (uint32_t)v; c = v >> 32; }
+    return r;
+}
+EC_DEV F256 u256_sub_wrap(const F256& a, const F256& b) {        // a - b mod 2^256
+    F256 r;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t d = (uint64_t)a.v[i] - b.v[i] - br;
+        r.v[i] = (uint32_t)d;
+        br = (d >> 32) & 1;
+    }
+    return r;
+}
+// |a| of a two's-complement value, sign in *neg
+EC_DEV F256 u256_abs(const F256& a, bool* neg) {
+    *neg = (a.v[7] >> 31) != 0;
+    F256 zero;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) zero.v[i] = 0;
+    const F256 m = u256_sub_wrap(zero, a);
+    F256 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = *neg ? m.v[i] : a.v[i];
+    return r;
+}
+
 EC_DEV uint64_t rol64(uint64_t v, int n) { return (v << n) | (v >> (64 - n)); }
 EC_DEV void keccak_f1600(uint64_t s[25]) {
     const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
@@ -554,9 +626,22 @@ EC_DEV void recover_lane(const uint8_t* rec, const RecoverConsts* K, const F256*
     F256 u2 = f_from_mont(f_mul(ri, f_to_mont(s, N), N), N);
     JPt acc;
     acc.x = zero; acc.y = zero; acc.y.v[0] = 1; acc.z = zero;
-    for (int bit = 255; bit >= 0; --bit) {            // u2 * R: double and add
-        acc = j_double(acc, P);
-        if ((u2.v[bit >> 5] >> (bit & 31)) & 1) acc = j_add_affine(acc, rx, ry, P);
+    {
+        // u2 * R = k1 * R + k2 * (beta * x(R), y(R)) with |k1|, |k2| < 2^128: 129 doublings instead of 256
+        const F256 c1 = u256_mul_shift384(u2, K->g1), c2 = u256_mul_shift384(u2, K->g2);
+        bool neg1, neg2;
+        const F256 k1 = u256_abs(u256_sub_wrap(u256_sub_wrap(u2, u256_mul_lo(c1, K->a1)), u256_mul_lo(c2, K->a2)), &neg1);
+        const F256 k2 = u256_abs(u256_sub_wrap(u256_mul_lo(c1, K->nb1), u256_mul_lo(c2, K->b2)), &neg2);
+        const F256 ny = f_sub(f_load_mod(P.m), ry, P);             // -y(R): y is not zero on this curve
+        const F256 rx2 = fp_mul(K->beta, rx, P);
+        F256 y1, y2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { y1.v[k] = neg1 ? ny.v[k] : ry.v[k]; y2.v[k] = neg2 ? ny.v[k] : ry.v[k]; }
+        for (int bit = 128; bit >= 0; --bit) {
+            acc = j_double(acc, P);
+            if ((k1.v[bit >> 5] >> (bit & 31)) & 1) acc = j_add_affine(acc, rx, y1, P);
+            if ((k2.v[bit >> 5] >> (bit & 31)) & 1) acc = j_add_affine(acc, rx2, y2, P);
+        }
     }
     for (int w = 0; w < 32; ++w) {                    // u1 * G: one table entry per byte of u1, no doublings
         const uint32_t d = (u1.v[w >> 2] >> (8 * (w & 3))) & 0xFFu;
@@ -629,6 +714,14 @@ static int build_consts(RecoverConsts& K) {
     put(K.gx.v, SECP_GX);
     put(K.gy.v, SECP_GY);
     put(K.seven.v, U256h{{7, 0, 0, 0}});
+    // secp256k1's endomorphism constants (public; beta^3 = 1 mod p, lambda^3 = 1 mod n, lambda * G = (beta * Gx, Gy))
+    put(K.beta.v, U256h{{0xc1396c28719501eeULL, 0x9cf0497512f58995ULL, 0x6e64479eac3434e9ULL, 0x7ae96a2b657c0710ULL}});
+    put(K.g1.v, U256h{{0xe893209a45dbb031ULL, 0x3daa8a1471e8ca7fULL, 0xe86c90e49284eb15ULL, 0x3086d221a7d46bcdULL}});
+    put(K.g2.v, U256h{{0x1571b4ae8ac47f71ULL, 0x221208ac9df506c6ULL, 0x6f547fa90abfe4c4ULL, 0xe4437ed6010e8828ULL}});
+    put(K.a1.v, U256h{{0xe86c90e49284eb15ULL, 0x3086d221a7d46bcdULL, 0, 0}});
+    put(K.a2.v, U256h{{0x57c1108d9d44cfd8ULL, 0x14ca50f7a8e2f3f6ULL, 1, 0}});
+    put(K.nb1.v, U256h{{0x6f547fa90abfe4c3ULL, 0xe4437ed6010e8828ULL, 0, 0}});
+    put(K.b2.v, U256h{{0xe86c90e49284eb15ULL, 0x3086d221a7d46bcdULL, 0, 0}});
     std::vector<FrRaw> rc_raw, mds_raw;
     poseidon5_parameters(rc_raw, mds_raw);
     if (rc_raw.size() != 340 || mds_raw.size() != 25) { set_error("internal: Poseidon parameter count"); return ET_E_UNSUPPORTED; }
