@@ -439,6 +439,45 @@ EC_DEV JPt j_add_affine(const JPt& p, const F256& qx, const F256& qy, const ModC
     return o;
 }
 
+// a^(n - 2) mod n for the secp256k1 group order n (Montgomery form in and out).  n - 2 is 127 ones, a zero and the
+// 128 bits of the order's low half minus 2: a ladder of a^(2^k - 1) for the ones (126 squarings, 12
+// multiplications), then the low half two bits at a time against a, a^2, a^3.
+EC_DEV F256 fn_sqr_n(F256 a, int k, const ModConst& N) {
+    for (int i = 0; i < k; ++i) a = f_mul(a, a, N);
+    return a;
+}
+EC_DEV F256 fn_inv(const F256& a, const ModConst& N) {
+    const F256 a2 = f_mul(fn_sqr_n(a, 1, N), a, N);              // 2^2 - 1
+    const F256 a3 = f_mul(fn_sqr_n(a2, 1, N), a, N);             // 2^3 - 1
+    const F256 a6 = f_mul(fn_sqr_n(a3, 3, N), a3, N);
+    const F256 a7 = f_mul(fn_sqr_n(a6, 1, N), a, N);
+    const F256 a14 = f_mul(fn_sqr_n(a7, 7, N), a7, N);
+    const F256 a15 = f_mul(fn_sqr_n(a14, 1, N), a, N);
+    const F256 a30 = f_mul(fn_sqr_n(a15, 15, N), a15, N);
+    const F256 a31 = f_mul(fn_sqr_n(a30, 1, N), a, N);
+    const F256 a62 = f_mul(fn_sqr_n(a31, 31, N), a31, N);
+    const F256 a63 = f_mul(fn_sqr_n(a62, 1, N), a, N);
+    const F256 a126 = f_mul(fn_sqr_n(a63, 63, N), a63, N);
+    F256 t = f_mul(fn_sqr_n(a126, 1, N), a, N);                  // 2^127 - 1
+    t = f_mul(t, t, N);                                          // the zero bit
+    const F256 sq = f_mul(a, a, N);                              // a^2; a^3 is a2
+    uint32_t low[4];                                             // low half of n - 2: limb 0 of n ends in ...41
+#pragma unroll
+    for (int i = 0; i < 4; ++i) low[i] = N.m[i];
+    low[0] -= 2;
+    for (int w = 63; w >= 0; --w) {
+        t = fn_sqr_n(t, 2, N);
+        const uint32_t d = (low[w >> 4] >> (2 * (w & 15))) & 3u;
+        if (d) {
+            F256 f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f.v[i] = d == 1 ? a.v[i] : (d == 2 ? sq.v[i] : a2.v[i]);
+            t = f_mul(t, f, N);
+        }
+    }
+    return t;
+}
+
 // ---- plain 256-bit helpers for the scalar split --------------------------------------------------------
 EC_DEV F256 u256_mul_lo(const F256& a, const F256& b) {          // a * b mod 2^256
     uint32_t t[8];
@@ -618,7 +657,7 @@ EC_DEV void recover_lane(const uint8_t* rec, const RecoverConsts* K, const F256*
     if ((ry.v[0] & 1u) != (y_odd ? 1u : 0u)) ry = f_sub(f_load_mod(P.m), ry, P);   // p - y (y != 0 on this curve)
 
     // ---- Q = u1 * G + u2 * R,  u1 = -hash / r,  u2 = s / r  (mod n) -----------------------------------------
-    F256 ri = f_inv(f_to_mont(r, N), N);
+    F256 ri = fn_inv(f_to_mont(r, N), N);
     F256 zero;
 #pragma unroll
     for (int k = 0; k < 8; ++k) zero.v[k] = 0;
