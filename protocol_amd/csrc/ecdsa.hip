@@ -94,17 +94,6 @@ EC_DEV bool f_geq(const F256& a, const uint32_t* m) {   // a >= m
     }
     return br == 0;
 }
-EC_DEV F256 f_sub_raw(const F256& a, const uint32_t* m) {
-    F256 r;
-    uint64_t br = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint64_t d = (uint64_t)a.v[i] - m[i] - br;
-        r.v[i] = (uint32_t)d;
-        br = (d >> 32) & 1;
-    }
-    return r;
-}
 // a - m when `force` is set or a >= m, else a: difference and borrow in one pass, limbs chosen without a branch.
 // (The form `if (a >= m) a = a - m;` on the whole struct came out wrong from the device compiler at -O2 and -O3 in
 // some inlining contexts: sums off by the modulus' low limb.  Every reduction here selects limb by limb instead.)
@@ -249,20 +238,6 @@ EC_DEV F256 f_from_mont(const F256& a, const ModConst& M) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) one.v[i] = i == 0 ? 1u : 0u;
     return f_mul(a, one, M);
-}
-// a^(m - k) for a small k: k = 2 is the inverse (Fermat), (m + 1) / 4 is handled by the caller's exponent
-EC_DEV F256 f_pow(const F256& a, const F256& e, const ModConst& M) {
-    F256 r = f_load_mod(M.one);
-    for (int i = 255; i >= 0; --i) {
-        r = f_mul(r, r, M);
-        if ((e.v[i >> 5] >> (i & 31)) & 1) r = f_mul(r, a, M);
-    }
-    return r;
-}
-EC_DEV F256 f_inv(const F256& a, const ModConst& M) {
-    F256 e = f_load_mod(M.m);   // m - 2: the moduli here all end in ...1 or ...f, so no borrow past limb 0
-    e.v[0] -= 2;
-    return f_pow(a, e, M);
 }
 
 // ---- secp256k1 base field, p = 2^256 - 2^32 - 977, plain (non-Montgomery) representation ------------------
