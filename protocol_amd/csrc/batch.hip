@@ -395,6 +395,8 @@ struct BatchArgsM {
     const uint32_t* colsum;  // n_sets * np : sum_j v_ji
     uint32_t np;             // n rounded up to a multiple of 64; blockDim.x == np
     U256 initial_m;          // INITIAL_SCORE * 2^256 mod r
+    uint32_t pack;           // sets per workgroup (k_batch_fr_mfma_packed), else 1
+    uint32_t n_sets;
 };
 
 // The two 32 x 32 result tiles of a wavefront (limb rows x columns), the tile against the matrix of ones and the
@@ -518,6 +520,73 @@ __global__ __launch_bounds__(KS * 32) __attribute__((amdgpu_waves_per_eu(3, 3)))
     }
 }
 
+// Sets of up to 32 slots (the reference's production set has 4): floor(64 / n) sets share ONE wavefront.  Their
+// opinion matrices sit on the diagonal of a 64 x 64 byte matrix, so the same two MFMA tiles multiply all of them
+// at once and every lane still owns one slot of one set; only the conservation check is per set.
+__global__ __launch_bounds__(64) void k_batch_fr_mfma_packed(BatchArgsM am) {
+    const BatchArgs& a = am.b;
+    constexpr uint32_t NP = 64, ROW = NP + MFMA_ROW_PAD, KS = 2;
+    __shared__ __attribute__((aligned(16))) uint8_t xsb[2][32 * ROW];
+    __shared__ uint4 s_l[2 * 64];
+    const uint32_t n = a.n, pack = am.pack, e = threadIdx.x;
+    const int r = e & 31, h = e >> 5;
+    const size_t first_set = (size_t)blockIdx.x * pack;
+    const uint32_t sets_here = (uint32_t)(am.n_sets - first_set < pack ? am.n_sets - first_set : pack);
+    const uint32_t n_eff = sets_here * n;
+    const size_t base = first_set * n;
+    const uint8_t* vt = reinterpret_cast<const uint8_t*>(a.vals) + (size_t)blockIdx.x * NP * NP;
+    v4i b0[KS], b1[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        b0[ks] = *reinterpret_cast<const v4i*>(vt + (size_t)r * NP + ks * 32 + 16 * h);
+        b1[ks] = *reinterpret_cast<const v4i*>(vt + (size_t)(32 + r) * NP + ks * 32 + 16 * h);
+    }
+    const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
+    const int kc0 = (int)(128u * am.colsum[(size_t)blockIdx.x * NP + r]);
+    const int kc1 = (int)(128u * am.colsum[(size_t)blockIdx.x * NP + 32 + r]);
+    // a set with fewer than two members (native.rs:289) computes nothing and reports its status
+    const bool is_member = e < n_eff && a.member[base + e] != 0 && a.pre_status[first_set + e / n] == ET_OK;
+    const U256 scale = is_member ? u256_load(a.scale + 2 * (base + e)) : u256_zero();
+    U256 s = is_member ? a.initial : u256_zero();
+    U256 sm = is_member ? am.initial_m : u256_zero();
+    for (uint32_t it = 0; it < a.num_iter; ++it) {
+        uint8_t* xb = xsb[it & 1];
+        Acc prod = acc_zero();
+        acc_mac(prod, sm, scale);
+        const U256 xs = acc_redc_loose<8>(prod);
+#pragma unroll
+        for (int l = 0; l < 32; ++l) xb[l * ROW + e] = (uint8_t)(((xs.v[l >> 2] >> (8 * (l & 3))) & 0xFFu) ^ 0x80u);
+        __syncthreads();
+        v16i acc0 = {0}, acc1 = {0}, acc2 = {0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const v4i x = *reinterpret_cast<const v4i*>(xb + r * ROW + ks * 32 + 16 * h);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, b0[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, b1[ks], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, ones, acc2, 0, 0, 0);
+        }
+        const Acc10 acc = mfma_tiles_to_column(acc0, acc1, acc2, kc0, kc1, h);
+        if (it + 1 == a.num_iter) s = is_member ? acc_redc288(acc_from_acc10(acc)) : u256_zero();
+        else sm = is_member ? acc_redc_loose<1>(acc_from_acc10(acc)) : u256_zero();
+    }
+    if (e < n_eff) u256_store(a.out + 2 * (base + e), s);
+    u256_store(s_l + 2 * e, s);
+    __syncthreads();
+    if (e < sets_here) {                                   // conservation per set (native.rs:331-334)
+        const size_t gs = first_set + e;
+        int32_t status = a.pre_status[gs];
+        if (status == ET_OK) {
+            U256 tot = u256_zero(), expect = u256_zero();
+            for (uint32_t k = 0; k < n; ++k) {
+                tot = fr_add(tot, u256_load(s_l + 2 * (e * n + k)));
+                if (a.member[gs * n + k]) expect = fr_add(expect, a.initial);
+            }
+            status = u256_eq(tot, expect) ? ET_OK : ET_E_SUM_MISMATCH;
+        }
+        a.status[gs] = status;
+    }
+}
+
 // The same for sets of up to 1024 slots, whose opinion bytes do not fit the registers of their wavefronts:
 // every k-step's two operands are read again from the transposed matrix in global memory (a set's matrix is
 // at most 1 MiB and stays in the caches over its 20 iterations); LDS holds the two copies of xs only.
@@ -603,6 +672,7 @@ struct DeviceBatch {
     bool vals_u8 = false;
     bool mfma = false;    // byte opinions and n <= 256: d_vals holds the transposed, sign-shifted matrix
     uint32_t np = 0;      // n rounded up to a multiple of 64 (mfma only)
+    uint32_t pack = 1;    // sets per workgroup: floor(64 / n) for sets of up to 32 slots (mfma only)
     uint32_t* d_colsum = nullptr;
     void* d_vals = nullptr;
     uint8_t* d_member = nullptr;
@@ -704,16 +774,20 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
         // [column i][source j] bytes of v_ji - 128, padded to np x np with v = 0; a peer without valid
         // opinions becomes a row of ones over the other members with factor inv(n_valid - 1) (native.rs:263-278)
         const uint32_t np = (n + 63) / 64 * 64;
+        const uint32_t pack = n <= 32 ? 64 / n : 1;      // small sets share a workgroup: block-diagonal matrix
+        const size_t n_groups = ((size_t)n_sets + pack - 1) / pack;
         b.np = np;
-        std::vector<uint8_t> vt((size_t)n_sets * np * np, 0x80);
-        std::vector<uint32_t> colsum((size_t)n_sets * np, 0);
+        b.pack = pack;
+        std::vector<uint8_t> vt(n_groups * np * np, 0x80);
+        std::vector<uint32_t> colsum(n_groups * np, 0);
         parallel_sets(n_sets, [&](uint32_t s) {
             if (pre[s] != ET_OK) return;
             const uint32_t* v = values + (size_t)s * n * n;
             const uint8_t* m = mem.data() + (size_t)s * n;
             const uint8_t* dg = dang.data() + (size_t)s * n;
-            uint8_t* o = vt.data() + (size_t)s * np * np;
-            uint32_t* cs = colsum.data() + (size_t)s * np;
+            const size_t corner = (size_t)(s % pack) * n;   // this set's corner on the diagonal of its group's matrix
+            uint8_t* o = vt.data() + (size_t)(s / pack) * np * np + corner * np + corner;
+            uint32_t* cs = colsum.data() + (size_t)(s / pack) * np + corner;
             uint32_t nv = 0;
             for (uint32_t i = 0; i < n; ++i) nv += m[i];
             // factors carry 2^288: the kernel multiplies them with scores that carry 2^256 and divides by 2^256
@@ -795,7 +869,10 @@ int et_batch_run_fr_async(et_batch* h, uint32_t num_iterations, uint64_t initial
         BatchArgsM am;
         am.b = a; am.colsum = b.d_colsum; am.np = b.np;
         am.initial_m = to_u256b(Fr::from_u128(initial_lo, initial_hi).pow2k(256).to_raw());
-        switch (b.np / 64) {
+        am.pack = b.pack; am.n_sets = b.n_sets;
+        if (b.pack > 1) {
+            hipLaunchKernelGGL(k_batch_fr_mfma_packed, dim3((b.n_sets + b.pack - 1) / b.pack), dim3(64), 0, st, am);
+        } else switch (b.np / 64) {
             case 1: hipLaunchKernelGGL((k_batch_fr_mfma<2>), dim3(b.n_sets), dim3(64), 0, st, am); break;
             case 2: hipLaunchKernelGGL((k_batch_fr_mfma<4>), dim3(b.n_sets), dim3(128), 0, st, am); break;
             case 3: hipLaunchKernelGGL((k_batch_fr_mfma<6>), dim3(b.n_sets), dim3(192), 0, st, am); break;

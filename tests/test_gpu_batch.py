@@ -20,6 +20,8 @@ def dense_expect(values, member, iters, initial):
                                           # byte opinions: every tile count of the matrix-core kernel with resident operands
                                           # (n <= 256), then the one that streams them (n <= 1024)
                                           (33, 4, 3), (100, 3, 255), (130, 2, 200), (192, 2, 255), (200, 2, 255),
+                                          # up to 32 slots: several sets share a wavefront (last group partly filled)
+                                          (4, 37, 255), (12, 11, 255), (32, 5, 255), (7, 20, 255), (2, 70, 255),
                                           (400, 2, 255), (1000, 1, 255)])
 def test_batch_matches_dense_restatement(n, n_sets, vmax):
     _check_batch(n, n_sets, vmax)
