@@ -2,8 +2,9 @@
 //
 // One workgroup per set; the whole converge of a set (dynamic_sets/native.rs:286-337) runs in ONE
 // launch.  Opinions that fit a byte (the production range, eigentrust/src/attestation.rs:304): the
-// dense product runs on the matrix cores as a product of byte limbs (k_batch_fr_mfma for sets of
-// up to 256 slots, k_batch_fr_mfma_stream up to 1024).  Larger opinions: k_batch_fr on the vector
+// dense product runs on the matrix cores as a product of byte limbs (k_batch_fr_mfma_packed for sets
+// of up to 32 slots, several per wavefront; k_batch_fr_mfma up to 256 slots; k_batch_fr_mfma_stream
+// up to 1024).  Larger opinions: k_batch_fr on the vector
 // ALUs with the trust vector in LDS; k_batch_fr_u8 is the byte-valued vector-ALU kernel the
 // matrix-core ones are measured against.
 // Sets never communicate, so a batch is split over GPUs by giving each its own sub-batch.
