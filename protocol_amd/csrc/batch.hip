@@ -769,6 +769,7 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
     // kernel only has to skip the diagonal
     const size_t cells = rows * n;
     b.vals_u8 = vmax.load() <= 255;
+    const Fr two288 = Fr::one().pow2k(288), two576 = Fr::one().pow2k(576);
     const char* no_mfma = getenv("ET_BATCH_NO_MFMA");   // measurement knob: the VALU kernel for small byte sets too
     b.mfma = b.vals_u8 && !(no_mfma && no_mfma[0] == '1');   // n <= 1024 was checked above
     if (b.mfma) {
@@ -779,34 +780,45 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
         const size_t n_groups = ((size_t)n_sets + pack - 1) / pack;
         b.np = np;
         b.pack = pack;
-        std::vector<uint8_t> vt(n_groups * np * np, 0x80);
+        const size_t vt_bytes = n_groups * np * np;
+        std::unique_ptr<uint8_t[]> vt(new uint8_t[vt_bytes]);     // every group's task fills its own matrix
         std::vector<uint32_t> colsum(n_groups * np, 0);
-        parallel_sets(n_sets, [&](uint32_t s) {
-            if (pre[s] != ET_OK) return;
-            const uint32_t* v = values + (size_t)s * n * n;
-            const uint8_t* m = mem.data() + (size_t)s * n;
-            const uint8_t* dg = dang.data() + (size_t)s * n;
-            const size_t corner = (size_t)(s % pack) * n;   // this set's corner on the diagonal of its group's matrix
-            uint8_t* o = vt.data() + (size_t)(s / pack) * np * np + corner * np + corner;
-            uint32_t* cs = colsum.data() + (size_t)(s / pack) * np + corner;
-            uint32_t nv = 0;
-            for (uint32_t i = 0; i < n; ++i) nv += m[i];
-            // factors carry 2^288: the kernel multiplies them with scores that carry 2^256 and divides by 2^256
-            const FrRaw uniform = Fr::from_u64(nv - 1).invert_or_zero().pow2k(288).to_raw();
-            for (uint32_t j = 0; j < n; ++j) {
-                if (!m[j]) continue;
-                FrRaw& f = scale[(size_t)s * n + j];
-                f = dg[j] ? uniform : Fr::from_raw(f).pow2k(288).to_raw();
-                for (uint32_t i = 0; i < n; ++i) {
-                    if (!m[i] || i == j) continue;
-                    const uint32_t x = dg[j] ? 1u : v[(size_t)j * n + i];
-                    o[(size_t)i * np + j] = (uint8_t)(x ^ 0x80u);
-                    cs[i] += x;
+        parallel_sets((uint32_t)n_groups, [&](uint32_t grp) {
+            uint8_t* gm = vt.get() + (size_t)grp * np * np;
+            std::memset(gm, 0x80, (size_t)np * np);
+            for (uint32_t s = grp * pack; s < std::min<uint64_t>((uint64_t)(grp + 1) * pack, n_sets); ++s) {
+                if (pre[s] != ET_OK) continue;
+                const uint32_t* v = values + (size_t)s * n * n;
+                const uint8_t* m = mem.data() + (size_t)s * n;
+                const uint8_t* dg = dang.data() + (size_t)s * n;
+                const size_t corner = (size_t)(s % pack) * n;   // this set's corner on the diagonal of its group's matrix
+                uint8_t* o = gm + corner * np + corner;
+                uint32_t* cs = colsum.data() + (size_t)grp * np + corner;
+                uint32_t nv = 0;
+                for (uint32_t i = 0; i < n; ++i) nv += m[i];
+                // factors carry 2^288: the kernel multiplies them with scores that carry 2^256 and divides by 2^256
+                const FrRaw uniform = (Fr::from_u64(nv - 1).invert_or_zero() * two288).to_raw();
+                for (uint32_t j = 0; j < n; ++j) {
+                    if (!m[j]) continue;
+                    FrRaw& f = scale[(size_t)s * n + j];
+                    f = dg[j] ? uniform : (Fr::from_raw(f) * two288).to_raw();
                 }
+                // transpose in 32 x 32 tiles so that reads and writes both stay in the cache
+                for (uint32_t jb = 0; jb < n; jb += 32)
+                    for (uint32_t ib = 0; ib < n; ib += 32)
+                        for (uint32_t j = jb; j < std::min(n, jb + 32); ++j) {
+                            if (!m[j]) continue;
+                            for (uint32_t i = ib; i < std::min(n, ib + 32); ++i) {
+                                if (!m[i] || i == j) continue;
+                                const uint32_t x = dg[j] ? 1u : v[(size_t)j * n + i];
+                                o[(size_t)i * np + j] = (uint8_t)(x ^ 0x80u);
+                                cs[i] += x;
+                            }
+                        }
             }
         });
-        HIP_TRY_B(hipMalloc(&b.d_vals, vt.size()));
-        HIP_TRY_B(hipMemcpy(b.d_vals, vt.data(), vt.size(), hipMemcpyHostToDevice));
+        HIP_TRY_B(hipMalloc(&b.d_vals, vt_bytes));
+        HIP_TRY_B(hipMemcpy(b.d_vals, vt.get(), vt_bytes, hipMemcpyHostToDevice));
         HIP_TRY_B(hipMalloc((void**)&b.d_colsum, colsum.size() * 4));
         HIP_TRY_B(hipMemcpy(b.d_colsum, colsum.data(), colsum.size() * 4, hipMemcpyHostToDevice));
     } else {
@@ -814,7 +826,7 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
         parallel_sets(n_sets, [&](uint32_t s) {
             for (uint32_t i = 0; i < n; ++i) {
                 FrRaw& f = scale[(size_t)s * n + i];
-                f = Fr::from_raw(f).pow2k(576).to_raw();
+                f = (Fr::from_raw(f) * two576).to_raw();
             }
         });
     }
