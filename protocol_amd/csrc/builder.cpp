@@ -241,12 +241,11 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     });
     std::vector<uint64_t> in_ptr((size_t)geo.rows_cap + 1, 0);
     run_threads(T, [&](unsigned t) {
-        const uint32_t r0 = (uint32_t)((uint64_t)geo.rows_cap * t / T), r1 = (uint32_t)((uint64_t)geo.rows_cap * (t + 1) / T);
-        for (uint32_t f = 0; f < n; ++f) {
+        for (uint32_t f = (uint32_t)((uint64_t)n * t / T); f < (uint32_t)((uint64_t)n * (t + 1) / T); ++f) {
             if (dangling[f]) continue;
             for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
                 const uint32_t lr = lr_of_edge[k];
-                if (lr >= r0 && lr < r1) in_ptr[lr + 1]++;
+                if (lr != 0xFFFFFFFFu) __atomic_fetch_add(&in_ptr[lr + 1], 1, __ATOMIC_RELAXED);
             }
         }
     });
@@ -305,6 +304,45 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         std::vector<uint64_t> bcur(g.bk_ptr.begin(), g.bk_ptr.end() - 1);
         std::vector<uint32_t> by_pos(order.begin(), order.begin() + n_active);
         std::sort(by_pos.begin(), by_pos.end(), [&](uint32_t a, uint32_t b) { return g.pos_of_ext[a] < g.pos_of_ext[b]; });
+        // Every thread walks ONE contiguous chunk of the attesters (ascending position, chunks of equal edge count)
+        // and drops each surviving edge into the bucket of the thread that owns its destination; a bucket therefore
+        // holds its edges in ascending source order, and its owner appends them to the rows (or workgroups) it owns.
+        std::vector<uint64_t> pos_edges((size_t)n_active + 1, 0);
+        for (uint32_t i = 0; i < n_active; ++i) pos_edges[i + 1] = pos_edges[i] + (out_ptr[by_pos[i] + 1] - out_ptr[by_pos[i]]);
+        std::vector<uint32_t> chunk_cut(T + 1, n_active);
+        chunk_cut[0] = 0;
+        for (unsigned t = 1; t < T; ++t)
+            chunk_cut[t] = (uint32_t)(std::lower_bound(pos_edges.begin(), pos_edges.end(), pos_edges[n_active] * t / T) - pos_edges.begin());
+        for (unsigned t = 1; t <= T; ++t) chunk_cut[t] = std::min<uint32_t>(n_active, std::max(chunk_cut[t], chunk_cut[t - 1]));
+        chunk_cut[T] = n_active;
+        struct Entry { uint32_t lr, pf; uint64_t k; };
+        auto scatter = [&](auto bucket_of, auto consume) {
+            std::vector<uint64_t> cnt((size_t)T * T, 0);
+            auto walk = [&](unsigned t, auto visit) {
+                for (uint32_t i = chunk_cut[t]; i < chunk_cut[t + 1]; ++i) {
+                    const uint32_t f = by_pos[i];
+                    uint32_t pf = g.pos_of_ext[f];
+                    pf = ((pf / geo.seg_stride()) << COL_SEG_SHIFT) | (pf % geo.seg_stride());
+                    for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
+                        const uint32_t lr = lr_of_edge[k];
+                        if (lr != 0xFFFFFFFFu) visit(lr, pf, k);
+                    }
+                }
+            };
+            run_threads(T, [&](unsigned t) { walk(t, [&](uint32_t lr, uint32_t, uint64_t) { ++cnt[(size_t)t * T + bucket_of(lr)]; }); });
+            std::vector<uint64_t> bucket_begin(T + 1, 0);
+            {
+                uint64_t run = 0;
+                for (unsigned d = 0; d < T; ++d) {
+                    bucket_begin[d] = run;
+                    for (unsigned t = 0; t < T; ++t) { const uint64_t c = cnt[(size_t)t * T + d]; cnt[(size_t)t * T + d] = run; run += c; }
+                }
+                bucket_begin[T] = run;
+            }
+            std::vector<Entry> buf(bucket_begin[T]);
+            run_threads(T, [&](unsigned t) { walk(t, [&](uint32_t lr, uint32_t pf, uint64_t k) { buf[cnt[(size_t)t * T + bucket_of(lr)]++] = Entry{lr, pf, k}; }); });
+            run_threads(T, [&](unsigned d) { for (uint64_t i = bucket_begin[d]; i < bucket_begin[d + 1]; ++i) consume(buf[i]); });
+        };
         // (a) per-row lists: thread t owns the rows whose edges fall in its share of the edge count
         std::vector<uint32_t> row_cut(T + 1, geo.rows_cap);
         row_cut[0] = 0;
@@ -312,36 +350,26 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
             row_cut[t] = (uint32_t)(std::lower_bound(in_ptr.begin(), in_ptr.end(), g.nnz_local * t / T) - in_ptr.begin());
         for (unsigned t = 1; t <= T; ++t) row_cut[t] = std::max(row_cut[t], row_cut[t - 1]);
         row_cut[T] = geo.rows_cap;
+        scatter([&](uint32_t lr) { return (unsigned)(std::upper_bound(row_cut.begin() + 1, row_cut.end() - 1, lr) - (row_cut.begin() + 1)); },
+                [&](const Entry& e) {
+                    const uint64_t p = cur[e.lr]++;
+                    e_src[p] = e.pf;
+                    e_idx[p] = kept[e.k];
+                });
         // (b) per-workgroup lists: thread t owns a contiguous range of workgroups
         const uint32_t B64 = geo.f64_blocks;
-        run_threads(2 * T, [&](unsigned tt) {
-            const bool rows_pass = tt < T;
-            const unsigned t = rows_pass ? tt : tt - T;
-            const uint32_t r0 = row_cut[t], r1 = row_cut[t + 1];
-            const uint32_t b0 = (uint32_t)((uint64_t)B64 * t / T), b1 = (uint32_t)((uint64_t)B64 * (t + 1) / T);
-            for (uint32_t f : by_pos) {
-                uint32_t pf = g.pos_of_ext[f];
-                pf = ((pf / geo.seg_stride()) << COL_SEG_SHIFT) | (pf % geo.seg_stride());
-                for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
-                    const uint32_t lr = lr_of_edge[k];
-                    if (lr == 0xFFFFFFFFu) continue;
-                    if (rows_pass) {
-                        if (lr < r0 || lr >= r1) continue;
-                        uint64_t p = cur[lr]++;
-                        e_src[p] = pf;
-                        e_idx[p] = kept[k];
-                    } else {
-                        const uint32_t grp = lr / BLOCK_GROUP, blk = d64.block[grp];
-                        if (blk < b0 || blk >= b1) continue;
-                        uint64_t q = bcur[blk]++;
-                        g.bk_col[q] = pf;
-                        g.bk_row[q] = (uint16_t)(d64.slot[grp] * BLOCK_GROUP + lr % BLOCK_GROUP);
-                        if (g.values_are_u32) g.bk_val_u32[q] = in.val_u32[kept[k]];
-                        else g.bk_val_fr[q] = in.val_fr[kept[k]];
-                    }
-                }
-            }
-        });
+        std::vector<uint32_t> owner_of_block(B64, 0);
+        for (unsigned t = 0; t < T; ++t)
+            for (uint32_t bb = (uint32_t)((uint64_t)B64 * t / T); bb < (uint32_t)((uint64_t)B64 * (t + 1) / T); ++bb) owner_of_block[bb] = t;
+        scatter([&](uint32_t lr) { return (unsigned)owner_of_block[d64.block[lr / BLOCK_GROUP]]; },
+                [&](const Entry& e) {
+                    const uint32_t grp = e.lr / BLOCK_GROUP;
+                    const uint64_t q = bcur[d64.block[grp]]++;
+                    g.bk_col[q] = e.pf;
+                    g.bk_row[q] = (uint16_t)(d64.slot[grp] * BLOCK_GROUP + e.lr % BLOCK_GROUP);
+                    if (g.values_are_u32) g.bk_val_u32[q] = in.val_u32[kept[e.k]];
+                    else g.bk_val_fr[q] = in.val_fr[kept[e.k]];
+                });
     }
     // ---- 8. slices -----------------------------------------------------------------------------
     const uint32_t long_row = opt.long_row ? opt.long_row : 128;
