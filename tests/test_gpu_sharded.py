@@ -70,3 +70,59 @@ def test_sharded_converge_matches_oracle(world):
     got = np.array(ret["damped"], dtype=np.longdouble)
     assert float(np.abs(got - dld).sum() / np.abs(dld).sum()) <= 1e-9
     assert ret["start"] == pa.fr_bytes_from_ints([1000 if m else 0 for m in member]).tobytes()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_all_shares_in_one_process(world):
+    """The kernels on the layouts of 4 and 8 shares (what the 4- and 8-GPU runs execute), every share held by
+    this one process and the exchange done as device copies of the segments."""
+    import torch
+    import c_oracle
+    import protocol_amd as pa
+    n = 60000
+    frm, to, val = pa.synth_graph(3, n, 16 * n, seed=9, value_max=255)
+    member = np.ones(n, dtype=np.uint8)
+    member[::89] = 0
+    iters = 20
+    rc, exp, nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000)
+    assert rc == 0
+    rc, _e64, eld, _r, _n, _s = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=iters,
+                                                             initial=1000.0, want_ld=True)
+    assert rc == 0
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    graphs = [pa.Graph(n, frm, to, value_u32=val, member=member, n_seg=world, seg=r, device=0) for r in range(world)]
+    vec_len = int(graphs[0].info.vec_len)
+    stride = vec_len // world
+    assert int(graphs[0].info.nnz) == nnz and sum(int(g.info.nnz_local) for g in graphs) == nnz
+
+    def exchange(vecs):
+        for r in range(world):
+            for q in range(world):
+                if q != r:
+                    vecs[q][r * stride:(r + 1) * stride].copy_(vecs[r][r * stride:(r + 1) * stride])
+
+    for kind in ("fr", "f64"):
+        shape, dt = ((vec_len, 4), torch.int64) if kind == "fr" else ((vec_len,), torch.float64)
+        xs = [torch.zeros(shape, dtype=dt, device=dev) for _ in graphs]
+        ys = [torch.zeros(shape, dtype=dt, device=dev) for _ in graphs]
+        for g, x in zip(graphs, xs):
+            (g.init_fr if kind == "fr" else g.init_f64)(x.data_ptr(), 1000, st)
+        exchange(xs)
+        for it in range(iters):
+            for g, x, y in zip(graphs, xs, ys):
+                if kind == "fr":
+                    g.step_fr(x.data_ptr(), y.data_ptr(), it, st, final=it + 1 == iters)
+                else:
+                    g.step_f64(x.data_ptr(), y.data_ptr(), it, 0.0, None, st, final=it + 1 == iters)
+            exchange(ys)
+            xs, ys = ys, xs
+        out = torch.zeros((n, 4), dtype=torch.int64, device=dev) if kind == "fr" else torch.zeros(n, dtype=torch.float64, device=dev)
+        (graphs[0].unpermute_fr if kind == "fr" else graphs[0].unpermute_f64)(xs[0].data_ptr(), out.data_ptr(), st)
+        torch.cuda.synchronize(dev)
+        if kind == "fr":
+            assert out.cpu().numpy().view(np.uint8).reshape(n, 32).tobytes() == exp.tobytes()
+        else:
+            got = out.cpu().numpy().astype(np.longdouble)
+            assert float(np.abs(got - eld).sum() / np.abs(eld).sum()) <= 1e-9

@@ -91,3 +91,57 @@ def test_two_rank_exchange_matches_oracle():
     assert ret["fr"] == c_oracle.fr_bytes_to_ints(exp)
     got = np.array(ret["f64"])
     assert np.abs(got - e64).sum() / np.abs(e64).sum() <= 1e-12
+
+
+def _case(seed, n):
+    rng = np.random.default_rng(seed)
+    member = (rng.random(n) > 0.05).astype(np.uint8)
+    deg = rng.poisson(5, n)
+    deg[rng.random(n) < 0.1] = 0
+    frm = np.repeat(np.arange(n, dtype=np.uint32), deg)
+    to = rng.integers(0, n, len(frm), dtype=np.uint32)
+    sel = rng.random(len(frm)) < 0.25
+    to[sel] = rng.integers(0, 2, sel.sum())
+    val = rng.integers(0, 256, len(frm), dtype=np.uint32)
+    return member, frm, to, val
+
+
+def test_four_and_eight_segment_layouts_in_one_process():
+    """The layouts of 4 and 8 shares (8 is the most the source encoding holds), all shares emulated in one
+    process with the exchange as a plain copy of segments."""
+    import c_oracle
+    import pytest
+    import protocol_amd as pa
+    from plan_emulator import SegmentEmulator
+    n, iters = 1500, 3
+    member, frm, to, val = _case(21, n)
+    rc, exp, _nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000)
+    assert rc == 0
+    rc, e64, _ld, _r, _n, _s = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000.0)
+    assert rc == 0
+    for world in (4, 8):
+        ems = [SegmentEmulator(pa.Plan(n, frm, to, value_u32=val, member=member, n_seg=world, seg=r, long_row=16, target_work=6))
+               for r in range(world)]
+        for field in (True, False):
+            xs = [em.init(1000 if field else 1000.0, field) for em in ems]
+
+            def exchange(vecs):
+                for r, em in enumerate(ems):
+                    seg = em.segment_slice()
+                    for q in range(world):
+                        if q != r:
+                            vecs[q][seg] = vecs[r][seg]
+            exchange(xs)
+            for _ in range(iters):
+                ys = [[0] * len(xs[0]) if field else np.zeros(len(xs[0])) for _ in ems]
+                for em, x, y in zip(ems, xs, ys):
+                    em.step(x, y, field)
+                exchange(ys)
+                xs = ys
+            got = ems[0].unpermute(xs[0], field)
+            if field:
+                assert got == c_oracle.fr_bytes_to_ints(exp), world
+            else:
+                assert np.abs(np.array(got) - e64).sum() / np.abs(e64).sum() <= 1e-12, world
+    with pytest.raises(pa.EigenTrustError):
+        pa.Plan(n, frm, to, value_u32=val, member=member, n_seg=9, seg=0)
