@@ -185,7 +185,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     for (uint32_t i = threadIdx.x; i < RB; i += 1024) acc_l[i] = 0.0;
     // score mass of dangling peers: fixed-order sum of every segment's partial sums
     double D = 0.0;
-    {
+    if (a.geo.n_dangling != 0) {
         const uint32_t total = a.geo.n_seg * a.geo.nd_cap;
         for (uint32_t t = lane; t < total; t += 64) {
             uint32_t sg = t / a.geo.nd_cap, k = t - sg * a.geo.nd_cap;
@@ -316,6 +316,15 @@ ET_DEV U256 fr_wave_sum(U256 v) {
 // unreduced).  Called by the first wavefront of a workgroup; followed by __syncthreads().
 ET_DEV void fr_dangling_mass(const uint4* __restrict__ x, const Geometry& geo, const U256& inv_nm1_w, int lane,
                              uint32_t* sh_d, uint32_t* sh_pd) {
+    if (geo.n_dangling == 0) {           // no peer without opinions anywhere: D = 0, nothing to read
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sh_d[i] = i < 8 ? FR_P[i] : 0u;
+#pragma unroll
+            for (int i = 0; i < 17; ++i) sh_pd[i] = 0u;
+        }
+        return;
+    }
     const uint32_t stride = geo.seg_stride();
     Acc d = acc_zero();
     const uint32_t total = geo.n_seg * geo.nd_cap;
