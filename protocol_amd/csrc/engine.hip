@@ -483,19 +483,29 @@ __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr_raw(StepArgsFr a) {
         const uint32_t len = sd.len;
         if (len > 0) {
             const uint32_t last = len - 1;
+            // the records of the next batch are asked for before this batch's gathers, so the two waits overlap
+            uint32_t c[U], v[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const size_t o = (size_t)min((uint32_t)i, last) * 64;
+                c[i] = cp[o];
+                v[i] = (uint32_t)i < len ? (uint32_t)vp[o] : 0u;
+            }
             for (uint32_t k = 0; k < len; k += U) {
-                uint32_t c[U], v[U];
+                uint32_t cn[U], vn[U];
 #pragma unroll
                 for (int i = 0; i < U; ++i) {
-                    const size_t o = (size_t)min(k + i, last) * 64;
-                    c[i] = cp[o];
-                    v[i] = k + i < len ? (uint32_t)vp[o] : 0u;
+                    const size_t o = (size_t)min(k + U + i, last) * 64;
+                    cn[i] = cp[o];
+                    vn[i] = k + U + i < len ? (uint32_t)vp[o] : 0u;
                 }
                 U256 xv[U];
 #pragma unroll
                 for (int i = 0; i < U; ++i) xv[i] = u256_load(a.x + 2 * ((size_t)(c[i] >> COL_SEG_SHIFT) * stride + (c[i] & COL_LOCAL_MASK)));
 #pragma unroll
                 for (int i = 0; i < U; ++i) acc10_mac_u32(acc, xv[i], v[i]);
+#pragma unroll
+                for (int i = 0; i < U; ++i) { c[i] = cn[i]; v[i] = vn[i]; }
             }
         }
         const uint32_t sh = slice_log2_lanes(sd.nrows);
