@@ -58,6 +58,7 @@ def bench_small_sets(args, world, rank, device, red):
     import torch.distributed as dist
     import protocol_amd as pa
 
+    C5_SETS, C5_SLOTS = args.c5_sets, args.c5_slots      # defaults: the 4096 x 256 configuration
     rng = np.random.default_rng(args.seed + 5)
     values = rng.integers(1, 256, (C5_SETS, C5_SLOTS, C5_SLOTS), dtype=np.uint32)
     member = np.ones((C5_SETS, C5_SLOTS), dtype=np.uint8)
@@ -126,7 +127,8 @@ def bench_small_sets(args, world, rank, device, red):
             "roofline": {"bound": "mfma", "achieved": C5_SETS * NUM_ITER * args.steps * 2.0 * 32 * C5_SLOTS * C5_SLOTS / elapsed / 1e12,
                          "peak": 5000.0, "unit": "TFLOP/s",
                          "frac": C5_SETS * NUM_ITER * args.steps * 2.0 * 32 * C5_SLOTS * C5_SLOTS / elapsed / 1e12 / 5000.0,
-                         "traffic": None, "kernel": "k_batch_fr_mfma<8>",
+                         "traffic": None,
+                         "kernel": "k_batch_fr_mfma_packed" if C5_SLOTS <= 32 else ("k_batch_fr_mfma" if C5_SLOTS <= 256 else "k_batch_fr_mfma_stream"),
                          "note": "integer ops of the byte-limb product; the kernel's bound is 32-bit VALU field arithmetic"},
             "cpu_baseline": cpu,
             "checks": {"all_status_ok": ok, "sampled_sets_bit_exact": ok},
@@ -146,6 +148,8 @@ def main():
     ap.add_argument("--variant", default="both", choices=["both", "f64", "fr"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--c5-sets", type=int, default=C5_SETS, help="small-set workload: number of sets")
+    ap.add_argument("--c5-slots", type=int, default=C5_SLOTS, help="small-set workload: slots per set (<= 1024)")
     args = ap.parse_args()
 
     import numpy as np
