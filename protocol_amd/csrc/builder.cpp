@@ -184,6 +184,28 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         geo.f64_rb = (even + even / 4 + 2) * BLOCK_GROUP;
         geo.f64_dblocks = dangling_blocks(B, geo.f64_rb / BLOCK_GROUP, geo.n_dangling_pad / BLOCK_GROUP / G);
         geo.nd_cap = std::max<uint32_t>(geo.nd_cap, (geo.f64_dblocks + 15) / 16 * 16);
+        // exact blocked sweep: whole rounds of 256 workgroups of about 2048 rows (64 bytes of LDS per row); only
+        // where it was measured to pay
+        geo.fr_blocks = geo.fr_rb = geo.fr_dblocks = 0;
+        bool bytes_only = in.val_u32 != nullptr && !getenv("ET_FR_ROW_PER_LANE");
+        if (bytes_only && G == 1 && geo.rows_cap >= (1u << 19) && geo.rows_cap <= (1u << 21)) {
+            uint32_t vmax = 0;
+            for (uint64_t k = 0; k < in.n_edges; ++k) vmax |= in.val_u32[k];
+            bytes_only = vmax <= 255;
+        }
+        if (bytes_only && G == 1 && geo.rows_cap >= (1u << 19) && geo.rows_cap <= (1u << 21)) {
+            const uint32_t Bf = (geo.rows_cap / 2048 + 255) / 256 * 256;
+            const uint32_t even_f = (n_groups + Bf - 1) / Bf;
+            // no spare accumulator slots: every workgroup holds exactly its share of the row groups (the deal still
+            // levels the edges to about 2 %), so that its 1024 threads finish the rows in two full passes
+            const uint32_t rb = even_f * BLOCK_GROUP;
+            if (rb <= 2432) {
+                geo.fr_blocks = Bf;
+                geo.fr_rb = rb;
+                geo.fr_dblocks = dangling_blocks(Bf, rb / BLOCK_GROUP, geo.n_dangling_pad / BLOCK_GROUP / G);
+                geo.nd_cap = std::max<uint32_t>(geo.nd_cap, (geo.fr_dblocks + 15) / 16 * 16);
+            }
+        }
     }
     g.geo = geo;
     if (G > 8 || geo.seg_stride() >= COL_LOCAL_MASK) {
@@ -370,6 +392,26 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
                     if (g.values_are_u32) g.bk_val_u32[q] = in.val_u32[kept[e.k]];
                     else g.bk_val_fr[q] = in.val_fr[kept[e.k]];
                 });
+        // (c) the workgroups of the exact blocked sweep, when the geometry asks for them
+        if (geo.fr_blocks) {
+            const Deal dfr = deal(geo.fr_blocks, geo.fr_rb / BLOCK_GROUP, geo.fr_dblocks, g.fb_grp, g.fb_ptr);
+            g.fb_col.resize(g.nnz_local);
+            g.fb_row.resize(g.nnz_local);
+            g.fb_val.resize(g.nnz_local);
+            std::vector<uint64_t> fcur(g.fb_ptr.begin(), g.fb_ptr.end() - 1);
+            const uint32_t BF = geo.fr_blocks;
+            std::vector<uint32_t> owner_fr(BF, 0);
+            for (unsigned t = 0; t < T; ++t)
+                for (uint32_t bb = (uint32_t)((uint64_t)BF * t / T); bb < (uint32_t)((uint64_t)BF * (t + 1) / T); ++bb) owner_fr[bb] = t;
+            scatter([&](uint32_t lr) { return (unsigned)owner_fr[dfr.block[lr / BLOCK_GROUP]]; },
+                    [&](const Entry& e) {
+                        const uint32_t grp = e.lr / BLOCK_GROUP;
+                        const uint64_t q = fcur[dfr.block[grp]]++;
+                        g.fb_col[q] = e.pf;
+                        g.fb_row[q] = (uint16_t)(dfr.slot[grp] * BLOCK_GROUP + e.lr % BLOCK_GROUP);
+                        g.fb_val[q] = (uint8_t)in.val_u32[kept[e.k]];
+                    });
+        }
     }
     // ---- 8. slices -----------------------------------------------------------------------------
     const uint32_t long_row = opt.long_row ? opt.long_row : 128;

@@ -64,6 +64,11 @@ struct HostGraph {
     std::vector<uint32_t> bk_col;       // source, (segment << 29) | local row
     std::vector<uint16_t> bk_row;       // row inside the workgroup's accumulator array
     std::vector<uint32_t> bk_val_u32;   // raw opinions (values_are_u32)
+    // the same arrangement for the exact blocked sweep (geo.fr_blocks workgroups of geo.fr_rb accumulator rows)
+    std::vector<uint64_t> fb_ptr;
+    std::vector<uint32_t> fb_grp, fb_col;
+    std::vector<uint16_t> fb_row;
+    std::vector<uint8_t> fb_val;
     std::vector<FrRaw> bk_val_fr;
     // Per-position source factors (zero for dangling / non-member / padding positions):
     std::vector<FrRaw> scale_fr;        // inv(row sum) * 2^576 mod r

@@ -54,6 +54,14 @@ struct DeviceGraph {
     uint32_t* d_bk_rec = nullptr;
     uint32_t* d_bk_cbase = nullptr;
     uint64_t* d_bk_cptr = nullptr;
+    // exact blocked sweep (geo.fr_blocks != 0): per-workgroup edge lists like the f64 ones
+    bool fr_blocked = false;
+    uint32_t n_fr_parts = 0;          // partial statistics per launch: workgroups of the blocked sweep, else wavefront work items
+    uint64_t* d_fb_ptr = nullptr;
+    uint32_t* d_fb_grp = nullptr;
+    uint32_t* d_fb_col = nullptr;
+    uint16_t* d_fb_row = nullptr;
+    uint8_t* d_fb_val = nullptr;
     uint4* d_wlo = nullptr;
     uint4* d_whi = nullptr;
     uint32_t* d_pos = nullptr;

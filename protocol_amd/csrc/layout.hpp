@@ -84,6 +84,9 @@ struct Geometry {
     // groups of dangling rows go to the first f64_dblocks workgroups only; workgroup b of those writes
     // partial-sum slot b of its segment, so nd_cap >= f64_dblocks
     uint32_t f64_dblocks;
+    // exact blocked sweep (byte opinions, one share, 512K to 2M rows; 0 workgroups = not used): the same deal with
+    // eight 64-bit column sums per row in LDS, so at most 2432 rows per workgroup
+    uint32_t fr_blocks, fr_rb, fr_dblocks;
     ET_HD uint32_t seg_stride() const { return rows_cap + nd_cap; }
     ET_HD uint32_t pos_of_col(uint32_t c) const { return (c >> COL_SEG_SHIFT) * seg_stride() + (c & COL_LOCAL_MASK); }
 };
