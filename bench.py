@@ -218,6 +218,7 @@ def main():
             # (a SIMD issues one full-rate wave64 instruction per 4 cycles; the 64-bit multiply-adds take longer, so
             # this is a lower bound) over 1024 SIMDs x the cycles of the launch
             fr_rec = rec["kernels"].get("k_step_fr", {})
+            traffic["fr_kernel"] = fr_rec.get("kernel")
             if "SQ_INSTS_VALU" in fr_rec:
                 traffic["fr_valu_issue_frac"] = fr_rec["SQ_INSTS_VALU"] * 4.0 / (1024 * fr_rec["GRBM_GUI_ACTIVE"] / 8.0)
 
@@ -237,8 +238,11 @@ def main():
         del src, dst
 
     # the exact variant runs as a blocked sweep for one share of 512K to 2M rows of byte opinions, else row per lane
-    fr_blocked = world == 1 and (1 << 19) <= int(info.rows_cap) <= (1 << 21) and "ET_FR_ROW_PER_LANE" not in os.environ
+    fr_blocked = int(info.exact_sweep_blocks) != 0
     fr_kernel = "k_step_fr_blocked" if fr_blocked else "k_step_fr_raw<u8>"
+    if traffic.get("fr_kernel") not in (None, fr_kernel):   # the counters on record are another kernel's
+        traffic.pop("k_step_fr", None)
+        traffic.pop("fr_valu_issue_frac", None)
     results = {}
     for variant in (["f64", "fr"] if args.variant == "both" else [args.variant]):
         if variant == "f64":

@@ -89,6 +89,8 @@ pub struct et_graph_info {
     pub nd_cap: u32,
     pub vec_len: u64,
     pub device_bytes: u64,
+    pub f64_sweep_blocks: u32,
+    pub exact_sweep_blocks: u32,
 }
 
 #[repr(C)]

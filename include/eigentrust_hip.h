@@ -147,6 +147,9 @@ typedef struct {
     uint32_t rows_cap, nd_cap; /* position-space geometry: segment = rows_cap + nd_cap entries   */
     uint64_t vec_len;       /* entries of one trust vector in position order (all segments)      */
     uint64_t device_bytes;  /* device memory held by this graph                                  */
+    uint32_t f64_sweep_blocks;   /* workgroups of the f64 blocked sweep (0: variant not prepared)     */
+    uint32_t exact_sweep_blocks; /* workgroups of the exact blocked sweep; 0: the exact variant runs
+                                    its row-per-lane kernel on this graph                             */
 } et_graph_info;
 
 /* Filter + normalise + lay out an attestation list (see et_set_update_op for the meaning of a

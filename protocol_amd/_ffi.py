@@ -51,7 +51,8 @@ class EtGraphInfo(C.Structure):
                 ("nnz", C.c_uint64), ("nnz_local", C.c_uint64), ("padded_local", C.c_uint64),
                 ("n_slices", C.c_uint32), ("n_work", C.c_uint32),
                 ("rows_cap", C.c_uint32), ("nd_cap", C.c_uint32),
-                ("vec_len", C.c_uint64), ("device_bytes", C.c_uint64)]
+                ("vec_len", C.c_uint64), ("device_bytes", C.c_uint64),
+                ("f64_sweep_blocks", C.c_uint32), ("exact_sweep_blocks", C.c_uint32)]
 
 
 class EtSliceDesc(C.Structure):

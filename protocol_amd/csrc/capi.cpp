@@ -176,6 +176,8 @@ int et_graph_info_get(const et_graph* g, et_graph_info* info) {
     info->n_slices = d->n_slices; info->n_work = d->n_work;
     info->rows_cap = d->geo.rows_cap; info->nd_cap = d->geo.nd_cap;
     info->vec_len = d->vec_len; info->device_bytes = d->device_bytes;
+    info->f64_sweep_blocks = d->n_f64_parts;
+    info->exact_sweep_blocks = d->fr_blocked ? d->geo.fr_blocks : 0;
     return ET_OK;
 }
 

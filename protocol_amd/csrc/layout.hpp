@@ -12,7 +12,8 @@
 // many in-edges gets a slice of its own (s = 6) whose 64 lanes each hold every 64th edge of that
 // one row and are summed across the wavefront.
 // f64 variant: one edge list per workgroup, sorted by source, for rows whose accumulators the
-// workgroup keeps in LDS ("blocked sweep", see engine.hip).
+// workgroup keeps in LDS ("blocked sweep", see engine.hip).  One share of 512K to 2M rows of byte
+// opinions keeps such lists for the exact variant too (eight 64-bit column sums per row in LDS).
 //
 // The peers gathered most often (highest out-degree) are placed first: the busiest part of the
 // trust vector is one contiguous prefix.

@@ -219,6 +219,41 @@ def test_one_row_receives_every_attestation():
     assert rel_l1(o64, eld) <= F64_TOL
 
 
+@pytest.mark.parametrize("row_per_lane", [False, True])
+def test_both_exact_kernels_above_half_a_million_rows(row_per_lane, monkeypatch):
+    """One share of 512K to 2M rows of byte opinions runs the exact variant as a blocked sweep; the row-per-lane
+    kernel stays selectable there.  Both against the C restatement on a graph with empty slots, peers without
+    opinions and three rows far longer than a workgroup's even share."""
+    if row_per_lane:
+        monkeypatch.setenv("ET_FR_ROW_PER_LANE", "1")
+    rng = np.random.default_rng(77)
+    n = 600000
+    member, frm, to, val = random_graph(rng, n, 6, 0.03, 0.05, 255, hub=True)
+    rc, exp, nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=6, initial=1000,
+                                                  n_threads=c_oracle.max_threads())
+    assert rc == 0
+    g = pa.Graph(n, frm, to, value_u32=val, member=member, variants=1)
+    assert g.info.nnz == nnz
+    assert (int(g.info.exact_sweep_blocks) == 0) == row_per_lane
+    assert np.array_equal(g.converge_fr(6, 1000), exp)
+    assert np.array_equal(g.converge_fr(1, 1000),
+                          c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=1, initial=1000,
+                                                      n_threads=c_oracle.max_threads())[1])
+
+
+def test_exact_sweep_is_not_chosen_outside_its_window():
+    # opinions above 255 at the same size keep the row-per-lane kernel
+    rng = np.random.default_rng(78)
+    n = 600000
+    member, frm, to, val = random_graph(rng, n, 3, 0.0, 0.02, 70000)
+    g = pa.Graph(n, frm, to, value_u32=val, member=member, variants=1)
+    assert int(g.info.exact_sweep_blocks) == 0
+    rc, exp, _nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=3, initial=1000,
+                                                   n_threads=c_oracle.max_threads())
+    assert rc == 0
+    assert np.array_equal(g.converge_fr(3, 1000), exp)
+
+
 def test_full_size_benchmark_graph_parity():
     """The graph the metric is quoted on (1M peers / 16M attestations, 20 iterations), whole result:
     exact variant bit for bit against the C restatement, f64 against its long-double restatement."""
