@@ -328,10 +328,19 @@ ET_DEV void fr_dangling_mass(const uint4* __restrict__ x, const Geometry& geo, c
     const uint32_t stride = geo.seg_stride();
     Acc d = acc_zero();
     const uint32_t total = geo.n_seg * geo.nd_cap;
-    for (uint32_t t = lane; t < total; t += 64) {
-        uint32_t sg = t / geo.nd_cap, k = t - sg * geo.nd_cap;
-        U256 p = u256_load(x + 2 * ((size_t)sg * stride + geo.rows_cap + k));
-        acc_add_u256(d, p);
+    for (uint32_t t0 = lane; t0 < total; t0 += 256) {     // four entries per lane in flight
+        U256 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t t = t0 + 64 * u;
+            p[u] = u256_zero();
+            if (t < total) {
+                const uint32_t sg = t / geo.nd_cap, k = t - sg * geo.nd_cap;
+                p[u] = u256_load(x + 2 * ((size_t)sg * stride + geo.rows_cap + k));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc_add_u256(d, p[u]);
     }
     acc_wave_sum(d);  // < 2^(254+log2(total)) : limbs 0..8
     Acc pd = acc_zero();
@@ -551,6 +560,13 @@ __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr_raw(StepArgsFr a) {
 // integers, any order), walks its edges in ascending source order like the f64 sweep -- so the gathered window of
 // the vector is shared through the L2 and every gather is an L2 hit -- and then folds, reduces and scales its
 // rows.  Uniform-source microbenchmark: 143 us against 271 us for the row-per-lane access pattern.
+//
+// Row arithmetic.  A row's folded sum T = new score * 2^288 (plus the dangling term, reduced once per workgroup)
+// stays below 2^288, so the exchanged entry new score * inv(sum) * 2^288 is ONE reduction of the 9 x 8-limb
+// product T * (inv(sum) * 2^288): 144 instead of 208 limb multiply-adds per row.  The plain score is only formed
+// on the final step; the score sum is the reduction of the integer sum of the T (reduction is linear), and a score
+// changed exactly when its exchanged entry did (the factor is invertible).  Rows of dangling peers keep their
+// plain scores in `own` as the row-per-lane kernel does.
 // ---------------------------------------------------------------------------------------------
 struct StepArgsFrB {
     const uint64_t* ptr;      // [fr_blocks + 1]
@@ -561,30 +577,58 @@ struct StepArgsFrB {
     const uint4* x;
     uint4* y;
     uint4* own;
-    const uint4* scale;
+    const uint4* scale288;    // inv(sum) * 2^288 per position
     uint4* sum_part;          // [fr_blocks][2]
     uint32_t* chg_part;       // [fr_blocks]
     Geometry geo;
     uint32_t final_step;
     U256 inv_nm1_w;
+    U256 inv_nm1_w576;        // inv(n_valid - 1) * 2^576
 };
+
+__global__ void k_scale_288(const uint4* __restrict__ scale576, uint4* __restrict__ scale288, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const U256 s = u256_load(scale576 + 2 * i);
+    Acc t = acc_zero();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t.v[k] = s.v[k];
+    u256_store(scale288 + 2 * i, acc_redc288(t));
+}
 
 __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     extern __shared__ unsigned long long colsum_l[];   // [8][RB]
     __shared__ uint32_t sh_d[9];
     __shared__ uint32_t sh_pd[17];
-    __shared__ uint4 red_l[2 * 2 * 16];
+    __shared__ uint32_t sh_pdr[8];
+    __shared__ uint4 red_l[2 * 16];
     __shared__ uint32_t red_c[16];
+    __shared__ uint32_t red_raw[16][10];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x, RB = a.geo.fr_rb;
     const uint32_t stride = a.geo.seg_stride();
     const size_t my_base = (size_t)a.geo.seg * stride;
     for (uint32_t i = threadIdx.x; i < 8 * RB; i += 1024) colsum_l[i] = 0;
-    if (wave == 0) fr_dangling_mass(a.x, a.geo, a.inv_nm1_w, lane, sh_d, sh_pd);
     __syncthreads();
+    // the first wavefront prepares the dangling term while the others already sweep; the workgroup next meets at
+    // the sweep's own barriers, and the term is read after the barrier that ends the sweep
+    if (wave == 0) {
+        // the product with inv(n_valid - 1) * 2^576, reduced once: inv(n_valid - 1) * D * 2^288 below r
+        fr_dangling_mass(a.x, a.geo, a.inv_nm1_w576, lane, sh_d, sh_pd);
+        if (lane == 0) {
+            Acc pd;
+#pragma unroll
+            for (int i = 0; i < 17; ++i) pd.v[i] = sh_pd[i];
+            const U256 pr = acc_redc288(pd);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sh_pdr[i] = pr.v[i];
+        }
+    }
 
     const uint64_t e0 = a.ptr[b], e1 = a.ptr[b + 1];
-    constexpr int U = 4;
+    // three edges per thread in flight and a barrier every second batch: 145 us on the 1M-peer benchmark graph against
+    // 153 us for four (150 us for two, 156 us without the barriers' help or with a barrier every batch)
+    constexpr int U = 3;
     const uint32_t n_batches = (uint32_t)((e1 - e0) / (U * 1024));
     uint64_t e = e0 + threadIdx.x;
     auto add_edge = [&](uint32_t slot, uint32_t v, const uint4& lo, const uint4& hi) {
@@ -613,53 +657,87 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
         for (int u = 0; u < U; ++u) add_edge(r[u], v[u], lo[u], hi[u]);
         if (k & 1) __syncthreads();
     }
-    for (; e < e1; e += 1024) {
-        const uint32_t c = a.col[e];
-        const uint4* p = a.x + 2 * ((size_t)(c >> COL_SEG_SHIFT) * stride + (c & COL_LOCAL_MASK));
-        add_edge(a.row[e], a.val[e], p[0], p[1]);
+    {   // the rest of the list as one more batch, its loads in flight together like the others'
+        uint32_t c[U], v[U], r[U];
+        uint4 lo[U], hi[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = e + u * 1024;
+            const bool in = i < e1;
+            c[u] = in ? a.col[i] : 0u;
+            v[u] = in ? a.val[i] : 0u;
+            r[u] = in ? a.row[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint4* p = a.x + 2 * ((size_t)(c[u] >> COL_SEG_SHIFT) * stride + (c[u] & COL_LOCAL_MASK));
+            lo[u] = p[0];
+            hi[u] = p[1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (e + u * 1024 < e1) add_edge(r[u], v[u], lo[u], hi[u]);
     }
     __syncthreads();
 
-    U256 tot = u256_zero(), dacc = u256_zero();
+    U256 dacc = u256_zero();                              // field sum of this thread's dangling rows' scores
+    Acc10 traw = acc10_zero();                            // integer sum of this thread's T
     uint32_t changed = 0;
-    // rows with opinions first (the common case, no dangling arithmetic in the loop), then the dangling rows, which
-    // only the leading workgroups hold
-    auto fold_row = [&](uint32_t lr, Acc& full) {
-        uint64_t c = 0;                                   // eight 64-bit column sums, 32 bits apart
+    // eight 64-bit column sums, 32 bits apart, as ten limbs
+    auto fold_row = [&](uint32_t lr, uint32_t* t) {
+        uint64_t c = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const unsigned long long t = colsum_l[lr + (size_t)j * RB];
-            c += t & 0xFFFFFFFFull;
-            full.v[j] = (uint32_t)c;
-            c = (c >> 32) + (t >> 32);
+            const unsigned long long s = colsum_l[lr + (size_t)j * RB];
+            c += s & 0xFFFFFFFFull;
+            t[j] = (uint32_t)c;
+            c = (c >> 32) + (s >> 32);
         }
-        full.v[8] = (uint32_t)c;
-        full.v[9] = (uint32_t)(c >> 32);
+        t[8] = (uint32_t)c;
+        t[9] = (uint32_t)(c >> 32);
     };
+    // rows with opinions first (the common case, no dangling arithmetic in the loop), then the dangling rows, which
+    // only the leading workgroups hold
     for (uint32_t lr = threadIdx.x; lr < RB; lr += 1024) {
         const uint32_t grp = a.grp[(size_t)b * (RB / BLOCK_GROUP) + lr / BLOCK_GROUP];
         if (grp == 0xFFFFFFFFu) continue;
         const uint32_t row = grp * BLOCK_GROUP + lr % BLOCK_GROUP;
         const uint64_t q = ((uint64_t)(row >> 6) * a.geo.n_seg + a.geo.seg) * 64 + (row & 63);
         if (q >= a.geo.n_active) continue;
-        Acc full = acc_zero();
-        fold_row(lr, full);
+        // T = sum of opinion * xs (below 2^24 * 2^8 * r) + dangling term (below r): limb 9 stays empty
+        uint32_t t[10];
+        fold_row(lr, t);
         {
-            uint64_t c = 0;                               // + inv(n_valid - 1) * D, unreduced
+            uint64_t c = 0;
 #pragma unroll
-            for (int i = 0; i < 17; ++i) {
-                c += (uint64_t)full.v[i] + sh_pd[i];
-                full.v[i] = (uint32_t)c;
+            for (int i = 0; i < 8; ++i) {
+                c += (uint64_t)t[i] + sh_pdr[i];
+                t[i] = (uint32_t)c;
                 c >>= 32;
             }
+            t[8] += (uint32_t)c;
         }
-        const U256 v = acc_redc288(full);
-        const U256 old = u256_load(a.own + 2 * (size_t)row);
-        u256_store(a.own + 2 * (size_t)row, v);
-        const U256 out = a.final_step ? v : fr_mul_redc288(v, u256_load(a.scale + 2 * (my_base + row)));
-        u256_store(a.y + 2 * (my_base + row), out);
-        changed += u256_eq(v, old) ? 0u : 1u;
-        tot = fr_add(tot, v);
+        {
+            uint64_t c = 0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                c += (uint64_t)traw.v[i] + t[i];
+                traw.v[i] = (uint32_t)c;
+                c >>= 32;
+            }
+            traw.v[9] += (uint32_t)c;
+        }
+        const U256 xs = acc_redc288(acc_mul_9x8(t, u256_load(a.scale288 + 2 * (my_base + row))));
+        const U256 old = u256_load(a.x + 2 * (my_base + row));
+        changed += u256_eq(xs, old) ? 0u : 1u;
+        if (a.final_step) {
+            Acc full = acc_zero();
+#pragma unroll
+            for (int i = 0; i < 9; ++i) full.v[i] = t[i];
+            u256_store(a.y + 2 * (my_base + row), acc_redc288(full));
+        } else {
+            u256_store(a.y + 2 * (my_base + row), xs);
+        }
     }
     if (b < a.geo.fr_dblocks) {
         for (uint32_t lr = threadIdx.x; lr < RB; lr += 1024) {
@@ -669,7 +747,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             const uint64_t q = ((uint64_t)(row >> 6) * a.geo.n_seg + a.geo.seg) * 64 + (row & 63);
             if (q < a.geo.n_active_pad || q >= (uint64_t)a.geo.n_active_pad + a.geo.n_dangling) continue;
             Acc full = acc_zero();
-            fold_row(lr, full);
+            fold_row(lr, full.v);
             const U256 old = u256_load(a.own + 2 * (size_t)row);
             fr_add_dangling_term(full, sh_d, old, a.inv_nm1_w);
             const U256 v = acc_redc288(full);
@@ -677,23 +755,42 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             // a dangling peer has no out-edges: its exchanged entry is never gathered
             u256_store(a.y + 2 * (my_base + row), a.final_step ? v : u256_zero());
             changed += u256_eq(v, old) ? 0u : 1u;
-            tot = fr_add(tot, v);
             dacc = fr_add(dacc, v);
         }
     }
-    tot = fr_wave_sum(tot);
-    dacc = fr_wave_sum(dacc);
+    // per wavefront: integer sum of the T, field sum of the dangling rows' scores (leading workgroups only), count
+    acc10_group_sum(traw, 64);
+    if (b < a.geo.fr_dblocks) dacc = fr_wave_sum(dacc);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) changed += __shfl_xor(changed, off, 64);
-    if (lane == 0) { u256_store(red_l + 2 * wave, tot); u256_store(red_l + 32 + 2 * wave, dacc); red_c[wave] = changed; }
+    if (lane == 0) {
+        u256_store(red_l + 2 * wave, dacc);
+        red_c[wave] = changed;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) red_raw[wave][i] = traw.v[i];
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        U256 t = u256_zero(), d = u256_zero();
+    // the first wavefront adds the sixteen partial results, one per lane
+    if (wave == 0) {
+        Acc10 r10 = acc10_zero();                         // at most 2432 rows below 2^287 each: ten limbs
+        U256 d = u256_zero();
         uint32_t ch = 0;
-        for (int w = 0; w < 16; ++w) { t = fr_add(t, u256_load(red_l + 2 * w)); d = fr_add(d, u256_load(red_l + 32 + 2 * w)); ch += red_c[w]; }
-        u256_store(a.sum_part + 2 * (size_t)b, t);
-        a.chg_part[b] = ch;
-        if (b < a.geo.fr_dblocks) u256_store(a.y + 2 * (my_base + a.geo.rows_cap + b), d);   // partial sum slot b
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) r10.v[i] = red_raw[lane][i];
+            d = u256_load(red_l + 2 * lane);
+            ch = red_c[lane];
+        }
+        acc10_group_sum(r10, 16);
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) ch += __shfl_xor(ch, off, 64);
+        if (b < a.geo.fr_dblocks) d = fr_wave_sum(d);
+        if (lane == 0) {
+            // score sum of the workgroup's rows: the dangling rows' plain scores plus the reduced integer sum
+            u256_store(a.sum_part + 2 * (size_t)b, fr_add(d, acc_redc288(acc_from_acc10(r10))));
+            a.chg_part[b] = ch;
+            if (b < a.geo.fr_dblocks) u256_store(a.y + 2 * (my_base + a.geo.rows_cap + b), d);   // partial sum slot b
+        }
     }
 }
 
@@ -774,7 +871,7 @@ static int dev_upload(T** p, const std::vector<T>& v, uint64_t& total) {
 DeviceGraph::~DeviceGraph() {
     if (device >= 0) (void)hipSetDevice(device);
     void* ptrs[] = {d_bk_ptr, d_bk_grp, d_bk_col, d_bk_row, d_bk_w, d_bk_rec, d_bk_cbase, d_bk_cptr, d_fb_ptr, d_fb_grp, d_fb_col, d_fb_row, d_fb_val, d_work, d_slices, d_col, d_val, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
-                    d_chg_part, d_stat_out, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust, d_scale64, d_scale_fr, own64, own_fr};
+                    d_chg_part, d_stat_out, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust, d_scale64, d_scale_fr, d_fb_scale, own64, own_fr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* e : ev_begin) (void)hipEventDestroy((hipEvent_t)e);
     for (void* e : ev_end) (void)hipEventDestroy((hipEvent_t)e);
@@ -915,6 +1012,10 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
                 (rc = dev_upload(&g->d_fb_col, h.fb_col, tot)) || (rc = dev_upload(&g->d_fb_row, h.fb_row, tot)) ||
                 (rc = dev_upload(&g->d_fb_val, h.fb_val, tot))) return rc;
             HIP_TRY(hipFuncSetAttribute((const void*)k_step_fr_blocked, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            // the sweep multiplies unreduced row sums by inv(sum) * 2^288 (the resident factors carry 2^576)
+            if ((rc = dev_alloc(&g->d_fb_scale, vec_len * 2, tot))) return rc;
+            hipLaunchKernelGGL(k_scale_288, dim3((unsigned)((vec_len + 255) / 256)), dim3(256), 0, 0, g->d_scale_fr, g->d_fb_scale, vec_len);
+            HIP_TRY(hipDeviceSynchronize());
         }
         if ((rc = dev_alloc(&g->out_fr, (size_t)h.n * 2, tot)) || (rc = dev_alloc(&g->d_frsum_part, (size_t)STATS_RING * g->n_fr_parts * 2, tot)) ||
             (rc = dev_alloc(&g->d_chg_part, (size_t)STATS_RING * g->n_fr_parts, tot))) return rc;
@@ -986,8 +1087,9 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
         StepArgsFrB fb;
         const size_t ringb = (size_t)(iteration % STATS_RING) * n_fr_parts;
         fb.ptr = d_fb_ptr; fb.grp = d_fb_grp; fb.col = d_fb_col; fb.row = d_fb_row; fb.val = d_fb_val; fb.x = x; fb.y = y;
-        fb.own = own_fr; fb.scale = d_scale_fr; fb.sum_part = d_frsum_part + 2 * ringb; fb.chg_part = d_chg_part + ringb;
+        fb.own = own_fr; fb.scale288 = d_fb_scale; fb.sum_part = d_frsum_part + 2 * ringb; fb.chg_part = d_chg_part + ringb;
         fb.geo = geo; fb.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u; fb.inv_nm1_w = to_u256(inv_nm1_w);
+        fb.inv_nm1_w576 = to_u256((Fr::from_raw(inv_nm1_w) * Fr::one().pow2k(288)).to_raw());
         hipLaunchKernelGGL(k_step_fr_blocked, dim3(geo.fr_blocks), dim3(1024), (size_t)geo.fr_rb * 64, st, fb);
         HIP_TRY(hipGetLastError());
         return ET_OK;

@@ -62,6 +62,7 @@ struct DeviceGraph {
     uint32_t* d_fb_col = nullptr;
     uint16_t* d_fb_row = nullptr;
     uint8_t* d_fb_val = nullptr;
+    uint4* d_fb_scale = nullptr;      // inv(sum) * 2^288 per position
     uint4* d_wlo = nullptr;
     uint4* d_whi = nullptr;
     uint32_t* d_pos = nullptr;

@@ -179,6 +179,33 @@ ET_DEV void acc_mac(Acc& acc, const U256& a, const U256& b) {
     }
     acc.v[16] += (uint32_t)cy;
 }
+// a (9 limbs, below 2^288) times b as a fresh 17-limb product: an unreduced row sum times a stored factor, so that
+// one reduction serves both
+ET_DEV Acc acc_mul_9x8(const uint32_t* a9, const U256& b) {
+    Acc p;
+    {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            uint64_t t = (uint64_t)a9[j] * b.v[0] + c;
+            p.v[j] = (uint32_t)t;
+            c = t >> 32;
+        }
+        p.v[9] = (uint32_t)c;
+    }
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            uint64_t t = (uint64_t)a9[j] * b.v[i] + p.v[i + j] + c;
+            p.v[i + j] = (uint32_t)t;
+            c = t >> 32;
+        }
+        p.v[i + 9] = (uint32_t)c;
+    }
+    return p;
+}
 // acc += a * v  (32-bit opinion times field element)
 ET_DEV void acc_mac_u32(Acc& acc, const U256& a, uint32_t v) {
     uint64_t c = 0;
