@@ -183,17 +183,19 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     const double* __restrict__ xr = a.x;
     const VT* __restrict__ wr = static_cast<const VT*>(a.w);
     for (uint32_t i = threadIdx.x; i < RB; i += 1024) acc_l[i] = 0.0;
-    // score mass of dangling peers: fixed-order sum of every segment's partial sums
-    double D = 0.0;
-    if (a.geo.n_dangling != 0) {
-        const uint32_t total = a.geo.n_seg * a.geo.nd_cap;
-        for (uint32_t t = lane; t < total; t += 64) {
-            uint32_t sg = t / a.geo.nd_cap, k = t - sg * a.geo.nd_cap;
-            D += xr[(size_t)sg * stride + a.geo.rows_cap + k];
+    // score mass of dangling peers: fixed-order sum of every segment's partial sums.  Only the rows' epilogue needs
+    // it: the first four entries per lane are requested here and added after the sweep, so their latency is hidden
+    const uint32_t d_total = a.geo.n_dangling != 0 ? a.geo.n_seg * a.geo.nd_cap : 0u;
+    double dv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t t = lane + 64 * u;
+        dv[u] = 0.0;
+        if (t < d_total) {
+            const uint32_t sg = t / a.geo.nd_cap, k = t - sg * a.geo.nd_cap;
+            dv[u] = xr[(size_t)sg * stride + a.geo.rows_cap + k];
         }
-        D = wave_sum_f64(D);
     }
-    const double dterm = D * a.inv_nm1;
     __syncthreads();
 
     const uint64_t e0 = a.bk_ptr[b], e1 = a.bk_ptr[b + 1];
@@ -242,39 +244,74 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     }
     __syncthreads();
 
+    double D = (dv[0] + dv[1]) + (dv[2] + dv[3]);
+    for (uint32_t t = lane + 256; t < d_total; t += 64) {
+        const uint32_t sg = t / a.geo.nd_cap, k = t - sg * a.geo.nd_cap;
+        D += xr[(size_t)sg * stride + a.geo.rows_cap + k];
+    }
+    D = wave_sum_f64(D);
+    const double dterm = D * a.inv_nm1;
     double res = 0.0, tot = 0.0, dacc = 0.0;
-    for (uint32_t lr = threadIdx.x; lr < RB; lr += 1024) {
-        const uint32_t grp = a.grp[(size_t)b * (RB / BLOCK_GROUP) + lr / BLOCK_GROUP];
-        if (grp == 0xFFFFFFFFu) continue;
-        const uint32_t row = grp * BLOCK_GROUP + lr % BLOCK_GROUP;
-        const uint64_t q = ((uint64_t)(row >> 6) * a.geo.n_seg + a.geo.seg) * 64 + (row & 63);
-        const bool active = q < a.geo.n_active;
-        const bool dang = q >= a.geo.n_active_pad && q < (uint64_t)a.geo.n_active_pad + a.geo.n_dangling;
-        if (!active && !dang) continue;
-        const double old = RAW ? a.own[row] : xr[my_base + row];
-        double v = dang ? acc_l[lr] + (D - old) * a.inv_nm1 : acc_l[lr] + dterm;
-        if (HAS_ALPHA) v = (1.0 - a.alpha) * v + a.alpha * a.pretrust[my_base + row];
-        if (RAW) {
-            a.own[row] = v;
-            a.y[my_base + row] = a.final_step ? v : v * a.scale[my_base + row];
-        } else {
-            a.y[my_base + row] = v;
+    // four rows per thread at a time: their group entries, then their old scores and factors are requested together
+    for (uint32_t lr0 = threadIdx.x; lr0 < RB; lr0 += 4 * 1024) {
+        uint32_t grp[4], row[4];
+        bool live[4], dang[4];
+        double old[4], sc[4], pt[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t lr = lr0 + u * 1024;
+            grp[u] = lr < RB ? a.grp[(size_t)b * (RB / BLOCK_GROUP) + lr / BLOCK_GROUP] : 0xFFFFFFFFu;
         }
-        res += fabs(v - old);
-        tot += v;
-        if (dang) dacc += v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t lr = lr0 + u * 1024;
+            row[u] = grp[u] * BLOCK_GROUP + lr % BLOCK_GROUP;
+            const uint64_t q = ((uint64_t)(row[u] >> 6) * a.geo.n_seg + a.geo.seg) * 64 + (row[u] & 63);
+            const bool active = q < a.geo.n_active;
+            dang[u] = q >= a.geo.n_active_pad && q < (uint64_t)a.geo.n_active_pad + a.geo.n_dangling;
+            live[u] = grp[u] != 0xFFFFFFFFu && (active || dang[u]);
+            old[u] = sc[u] = pt[u] = 0.0;
+            if (live[u]) {
+                old[u] = RAW ? a.own[row[u]] : xr[my_base + row[u]];
+                if (RAW && !a.final_step) sc[u] = a.scale[my_base + row[u]];
+                if (HAS_ALPHA) pt[u] = a.pretrust[my_base + row[u]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!live[u]) continue;
+            const double s = acc_l[lr0 + u * 1024];
+            double v = dang[u] ? s + (D - old[u]) * a.inv_nm1 : s + dterm;
+            if (HAS_ALPHA) v = (1.0 - a.alpha) * v + a.alpha * pt[u];
+            if (RAW) {
+                a.own[row[u]] = v;
+                a.y[my_base + row[u]] = a.final_step ? v : v * sc[u];
+            } else {
+                a.y[my_base + row[u]] = v;
+            }
+            res += fabs(v - old[u]);
+            tot += v;
+            if (dang[u]) dacc += v;
+        }
     }
     res = wave_sum_f64(res);
     tot = wave_sum_f64(tot);
     dacc = wave_sum_f64(dacc);
     if (lane == 0) { red[0][wave] = res; red[1][wave] = tot; red[2][wave] = dacc; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double r = 0.0, t = 0.0, d = 0.0;
-        for (int w = 0; w < 16; ++w) { r += red[0][w]; t += red[1][w]; d += red[2][w]; }
-        a.res_part[b] = r;
-        a.sum_part[b] = t;
-        if (b < a.geo.f64_dblocks) a.y[my_base + a.geo.rows_cap + b] = d;   // partial sum slot b of this segment
+    if (wave == 0) {                                       // sixteen partial results, one per lane
+        double r = lane < 16 ? red[0][lane] : 0.0, t = lane < 16 ? red[1][lane] : 0.0, d = lane < 16 ? red[2][lane] : 0.0;
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            r += __shfl_xor(r, off, 64);
+            t += __shfl_xor(t, off, 64);
+            d += __shfl_xor(d, off, 64);
+        }
+        if (lane == 0) {
+            a.res_part[b] = r;
+            a.sum_part[b] = t;
+            if (b < a.geo.f64_dblocks) a.y[my_base + a.geo.rows_cap + b] = d;   // partial sum slot b of this segment
+        }
     }
 }
 
