@@ -764,7 +764,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             }
             traw.v[9] += (uint32_t)c;
         }
-        const U256 xs = acc_redc288(acc_mul_9x8(t, u256_load(a.scale288 + 2 * (my_base + row))));
+        const U256 xs = fr_mul9_redc288(t, u256_load(a.scale288 + 2 * (my_base + row)));
         const U256 old = u256_load(a.x + 2 * (my_base + row));
         changed += u256_eq(xs, old) ? 0u : 1u;
         if (a.final_step) {

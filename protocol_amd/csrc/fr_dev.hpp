@@ -206,6 +206,48 @@ ET_DEV Acc acc_mul_9x8(const uint32_t* a9, const U256& b) {
     }
     return p;
 }
+// Column accumulator of the product-scanning forms below: 96 bits as a 64-bit pair, which is the multiply-add's own
+// addend, plus the count of its carries.
+ET_DEV void col_mac(uint64_t& lohi, uint32_t& top, uint32_t a, uint32_t b) {
+    // the multiply-add's carry-out goes straight into the third word: two instructions per limb product
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lohi), "+v"(top) : "v"(a), "v"(b) : "vcc");
+}
+ET_DEV uint32_t col_shift(uint64_t& lohi, uint32_t& top) {
+    const uint32_t out = (uint32_t)lohi;
+    lohi = (lohi >> 32) | ((uint64_t)top << 32);
+    top = 0;
+    return out;
+}
+// a (9 limbs, below 2^288) * b * 2^-288 mod r, canonical: the product acc_mul_9x8 and the reduction acc_redc288 in
+// one pass over the columns (limb i of the multiplier m is fixed when column i is complete), so that no partial
+// product is written back and no 32-bit carry travels on its own.  Requires b < r.
+ET_DEV U256 fr_mul9_redc288(const uint32_t* a9, const U256& b) {
+    uint64_t lohi = 0;
+    uint32_t top = 0;
+    uint32_t m[9];
+    U256 r;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int k = i - j;
+            if (k >= 0 && k < 8) col_mac(lohi, top, a9[j], b.v[k]);
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int k = i - j;
+            if (j < i && k >= 0 && k < 8) col_mac(lohi, top, m[j], FR_P[k]);
+        }
+        if (i < 9) {
+            m[i] = (uint32_t)lohi * FR_N0_32;
+            col_mac(lohi, top, m[i], FR_P[0]);               // the column's low word becomes zero
+            (void)col_shift(lohi, top);
+        } else {
+            r.v[i - 9] = col_shift(lohi, top);
+        }
+    }
+    return u256_sub_p_if_geq(r);
+}
 // acc += a * v  (32-bit opinion times field element)
 ET_DEV void acc_mac_u32(Acc& acc, const U256& a, uint32_t v) {
     uint64_t c = 0;
