@@ -479,9 +479,7 @@ __global__ __launch_bounds__(KS * 32) __attribute__((amdgpu_waves_per_eu(3, 3)))
     for (uint32_t it = 0; it < a.num_iter; ++it) {
         uint8_t* xb = xsb[it & 1];
         // xs_e as 32 bytes, one row of LDS per limb
-        Acc prod = acc_zero();
-        acc_mac(prod, sm, scale);
-        const U256 xs = acc_redc_loose<8>(prod);
+        const U256 xs = fr_mul_redc_loose8(sm, scale);
 #pragma unroll
         for (int l = 0; l < 32; ++l) xb[l * ROW + e] = (uint8_t)(((xs.v[l >> 2] >> (8 * (l & 3))) & 0xFFu) ^ 0x80u);
         __syncthreads();
@@ -552,9 +550,7 @@ __global__ __launch_bounds__(64) void k_batch_fr_mfma_packed(BatchArgsM am) {
     U256 sm = is_member ? am.initial_m : u256_zero();
     for (uint32_t it = 0; it < a.num_iter; ++it) {
         uint8_t* xb = xsb[it & 1];
-        Acc prod = acc_zero();
-        acc_mac(prod, sm, scale);
-        const U256 xs = acc_redc_loose<8>(prod);
+        const U256 xs = fr_mul_redc_loose8(sm, scale);
 #pragma unroll
         for (int l = 0; l < 32; ++l) xb[l * ROW + e] = (uint8_t)(((xs.v[l >> 2] >> (8 * (l & 3))) & 0xFFu) ^ 0x80u);
         __syncthreads();
@@ -618,9 +614,7 @@ __global__ __launch_bounds__(1024) void k_batch_fr_mfma_stream(BatchArgsM am) {
 
     for (uint32_t it = 0; it < a.num_iter; ++it) {
         uint8_t* xb = xsb_dyn + (size_t)(it & 1) * 32 * ROW;
-        Acc prod = acc_zero();
-        acc_mac(prod, sm, scale);
-        const U256 xs = acc_redc_loose<8>(prod);
+        const U256 xs = fr_mul_redc_loose8(sm, scale);
 #pragma unroll
         for (int l = 0; l < 32; ++l) xb[l * ROW + e] = (uint8_t)(((xs.v[l >> 2] >> (8 * (l & 3))) & 0xFFu) ^ 0x80u);
         __syncthreads();
