@@ -285,21 +285,31 @@ EC_DEV F256 fp_reduce512(const uint32_t* t, const ModConst& P) {
     for (int i = 0; i < 8; ++i) o.v[i] = r[i];
     return f_cond_sub(o, P.m, false);
 }
+// (top:lohi) += a * b: the multiply-add takes the 64-bit column sum as its own addend and its carry-out is counted in
+// the third word, two instructions per limb product
+EC_DEV void ec_col_mac(uint64_t& lohi, uint32_t& top, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lohi), "+v"(top) : "v"(a), "v"(b) : "vcc");
+#else       // the host build of the same functions (the checker of the device results)
+    const uint64_t r = (uint64_t)a * b + lohi;
+    top += r < lohi ? 1u : 0u;
+    lohi = r;
+#endif
+}
 EC_DEV F256 fp_mul(const F256& a, const F256& b, const ModConst& P) {
     uint32_t t[16];
-    {
-        uint64_t c = 0;
+    uint64_t lohi = 0;
+    uint32_t top = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { uint64_t v = (uint64_t)a.v[j] * b.v[0] + c; t[j] = (uint32_t)v; c = v >> 32; }
-        t[8] = (uint32_t)c;
+    for (int k = 0; k < 15; ++k) {                // column k of the product, complete before the next one starts
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k - j >= 0 && k - j < 8) ec_col_mac(lohi, top, a.v[j], b.v[k - j]);
+        t[k] = (uint32_t)lohi;
+        lohi = (lohi >> 32) | ((uint64_t)top << 32);
+        top = 0;
     }
-#pragma unroll
-    for (int i = 1; i < 8; ++i) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { uint64_t v = (uint64_t)a.v[j] * b.v[i] + t[i + j] + c; t[i + j] = (uint32_t)v; c = v >> 32; }
-        t[i + 8] = (uint32_t)c;
-    }
+    t[15] = (uint32_t)lohi;
     return fp_reduce512(t, P);
 }
 EC_DEV F256 fp_sqr(const F256& a, const ModConst& P) {
