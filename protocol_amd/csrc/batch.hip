@@ -866,6 +866,7 @@ void et_batch_free(et_batch* b) { delete b; }
 int et_batch_run_fr_async(et_batch* h, uint32_t num_iterations, uint64_t initial_lo, uint64_t initial_hi, void* stream) {
     if (!h) return ET_E_INVALID_ARG;
     DeviceBatch& b = h->b;
+    HIP_TRY_B(hipSetDevice(b.device));
     BatchArgs a;
     a.vals = b.d_vals; a.member = b.d_member; a.dangling = b.d_dangling; a.scale = b.d_scale; a.inv_nm1_w = b.d_inw;
     a.pre_status = b.d_pre; a.out = b.d_out; a.status = b.d_status; a.n = b.n; a.num_iter = num_iterations;
@@ -927,6 +928,7 @@ int et_batch_run_fr_async(et_batch* h, uint32_t num_iterations, uint64_t initial
 int et_batch_result_fr(et_batch* h, et_fr* out, int32_t* status, void* stream) {
     if (!h || !out) return ET_E_INVALID_ARG;
     DeviceBatch& b = h->b;
+    HIP_TRY_B(hipSetDevice(b.device));
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY_B(hipMemcpyAsync(out, b.d_out, (size_t)b.n_sets * b.n * 32, hipMemcpyDeviceToHost, st));
     if (status) HIP_TRY_B(hipMemcpyAsync(status, b.d_status, (size_t)b.n_sets * 4, hipMemcpyDeviceToHost, st));

@@ -237,27 +237,33 @@ int et_graph_converge_f64(et_graph* g, uint32_t num_iterations, double initial, 
 
 int et_graph_init_fr_async(et_graph* g, uint64_t lo, uint64_t hi, void* x, uint32_t flags, void* stream) {
     if (!g || !x) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->init_fr(lo, hi, (uint4*)x, (hipStream_t)stream, (flags & ET_INIT_PLAIN) != 0);
 }
 int et_graph_init_f64_async(et_graph* g, double initial, void* x, uint32_t flags, void* stream) {
     if (!g || !x) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->init_f64(initial, (double*)x, (hipStream_t)stream, (flags & ET_INIT_PLAIN) != 0);
 }
 int et_graph_step_fr_async(et_graph* g, const void* x, void* y, uint32_t iteration, uint32_t flags, void* stream) {
     if (!g || !x || !y) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->step_fr((const uint4*)x, (uint4*)y, iteration, flags, (hipStream_t)stream);
 }
 int et_graph_step_f64_async(et_graph* g, const void* x, void* y, uint32_t iteration, double alpha,
                             const void* pretrust_pos, uint32_t flags, void* stream) {
     if (!g || !x || !y) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->step_f64((const double*)x, (double*)y, iteration, alpha, (const double*)pretrust_pos, flags, (hipStream_t)stream);
 }
 int et_graph_unpermute_fr_async(et_graph* g, const void* x, void* out_slots, void* stream) {
     if (!g || !x || !out_slots) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->unpermute_fr((const uint4*)x, (uint4*)out_slots, (hipStream_t)stream);
 }
 int et_graph_unpermute_f64_async(et_graph* g, const void* x, void* out_slots, void* stream) {
     if (!g || !x || !out_slots) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->unpermute_f64((const double*)x, (double*)out_slots, (hipStream_t)stream);
 }
 int et_graph_permute_f64_host(const et_graph* g, const double* slots, double* pos) {
@@ -270,35 +276,43 @@ int et_graph_permute_f64_host(const et_graph* g, const double* slots, double* po
 }
 int et_graph_stats_fr(et_graph* g, uint32_t iteration, void* stream, et_iter_stats* out) {
     if (!g || !out) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->stats_fr(iteration, (hipStream_t)stream, out);
 }
 int et_graph_stats_f64(et_graph* g, uint32_t iteration, void* stream, et_iter_stats* out) {
     if (!g || !out) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->stats_f64(iteration, (hipStream_t)stream, out);
 }
 int et_graph_run_fr(et_graph* g, uint32_t num_iterations, uint64_t lo, uint64_t hi, void* stream, int record_events) {
     if (!g) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->run_fr(num_iterations, lo, hi, (hipStream_t)stream, record_events != 0);
 }
 int et_graph_run_f64(et_graph* g, uint32_t num_iterations, double initial, double alpha, void* stream, int record_events) {
     if (!g) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->run_f64(num_iterations, initial, alpha, (hipStream_t)stream, record_events != 0);
 }
 int et_graph_record_begin(et_graph* g, void* stream) {
     if (!g) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->record_begin((hipStream_t)stream);
 }
 int et_graph_record_end(et_graph* g, void* stream) {
     if (!g) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->record_end((hipStream_t)stream);
 }
 int et_graph_event_times(et_graph* g, float* total_ms, uint32_t* pairs) {
     if (!g) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->event_times(total_ms, pairs);
 }
 int et_graph_result_fr(et_graph* g, et_fr* out, void* stream) {
     if (!g || !out) return ET_E_INVALID_ARG;
     DeviceGraph* d = G(g);
+    HIP_TRY_C(hipSetDevice(d->device));
     if (!d->out_fr) return ET_E_UNSUPPORTED;
     HIP_TRY_C(hipMemcpyAsync(out, d->out_fr, (size_t)d->n * 32, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY_C(hipStreamSynchronize((hipStream_t)stream));
@@ -307,6 +321,7 @@ int et_graph_result_fr(et_graph* g, et_fr* out, void* stream) {
 int et_graph_result_f64(et_graph* g, double* out, void* stream) {
     if (!g || !out) return ET_E_INVALID_ARG;
     DeviceGraph* d = G(g);
+    HIP_TRY_C(hipSetDevice(d->device));
     if (!d->out_f64) return ET_E_UNSUPPORTED;
     HIP_TRY_C(hipMemcpyAsync(out, d->out_f64, (size_t)d->n * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY_C(hipStreamSynchronize((hipStream_t)stream));

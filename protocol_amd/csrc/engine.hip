@@ -183,6 +183,10 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     const double* __restrict__ xr = a.x;
     const VT* __restrict__ wr = static_cast<const VT*>(a.w);
     for (uint32_t i = threadIdx.x; i < RB; i += 1024) acc_l[i] = 0.0;
+    // the step owns the whole partial-sum tail of its segment of y: slots no workgroup writes are set to zero, so the
+    // next step's sum over all nd_cap slots never reads what the caller's allocation happened to hold
+    if (b == 0)
+        for (uint32_t k = a.geo.f64_dblocks + threadIdx.x; k < a.geo.nd_cap; k += 1024) a.y[my_base + a.geo.rows_cap + k] = 0.0;
     // score mass of dangling peers: fixed-order sum of every segment's partial sums.  Only the rows' epilogue needs
     // it: the first four entries per lane are requested here and added after the sweep, so their latency is hidden
     const uint32_t d_total = a.geo.n_dangling != 0 ? a.geo.n_seg * a.geo.nd_cap : 0u;
@@ -333,9 +337,19 @@ struct StepArgsFr {
     uint32_t* chg_part;    // [n_work]
     Geometry geo;
     uint32_t n_work;
+    uint32_t n_dslots;     // partial-sum slots of this segment's tail that the launch writes (dangling work items)
     uint32_t final_step;
     U256 inv_nm1_w;        // inv(n_valid-1) * 2^288 mod r
 };
+
+// A step owns the whole partial-sum tail of its segment of y: the slots no workgroup of this launch writes are
+// set to zero by the first workgroup, so that the next step's sum over all nd_cap slots never reads what a
+// caller's allocation happened to hold.
+ET_DEV void fr_zero_unused_tail(uint4* __restrict__ y, const Geometry& geo, uint32_t written, uint32_t threads) {
+    if (blockIdx.x != 0) return;
+    const size_t tail = (size_t)geo.seg * geo.seg_stride() + geo.rows_cap;
+    for (uint32_t k = written + threadIdx.x; k < geo.nd_cap; k += threads) u256_store(y + 2 * (tail + k), u256_zero());
+}
 
 ET_DEV U256 fr_wave_sum(U256 v) {
 #pragma unroll
@@ -444,32 +458,39 @@ __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr(StepArgsFr a) {
     const int wave = threadIdx.x >> 6;
     const uint32_t stride = a.geo.seg_stride();
     const size_t my_base = (size_t)a.geo.seg * stride;
-    // The first wavefront prepares the dangling mass while the others already walk their first slice;
-    // the workgroup meets once, before the first row is finished (wavefronts without a work item have
-    // left by then and do not count at the barrier).
+    fr_zero_unused_tail(a.y, a.geo, a.n_dslots, WPB_FR * 64);
+    // The first wavefront prepares the dangling mass while the others already walk their first slice.  Every
+    // wavefront of the workgroup stays alive (one without a work item walks no slice) and all of them meet at
+    // ONE barrier, after the first slice's edges and before its rows are finished.
     if (wave == 0) fr_dangling_mass(a.x, a.geo, a.inv_nm1_w, lane, sh_d, sh_pd);
     const uint32_t gw = blockIdx.x * WPB_FR + wave;
-    if (gw >= a.n_work) return;
-    const WorkDesc wd = a.work[gw];
+    const bool has_work = gw < a.n_work;
+    const WorkDesc wd = has_work ? a.work[gw] : WorkDesc{0u, 0u, 0u, 0u};
     const bool dang = (wd.flags & WORK_DANGLING) != 0;
     U256 tot = u256_zero(), dacc = u256_zero();
     uint32_t changed = 0;
-    for (uint32_t s = wd.slice_begin; s < wd.slice_end; ++s) {
-        const SliceDesc sd = a.slices[s];
-        const uint32_t* __restrict__ cp = a.col + (size_t)sd.off * 64 + lane;
-        const uint4* __restrict__ lop = a.wlo + (size_t)sd.off * 64 + lane;
-        const uint4* __restrict__ hip_ = a.whi + (size_t)sd.off * 64 + lane;
+    bool met = false;
+    for (uint32_t s = wd.slice_begin;; ++s) {
+        const bool have = s < wd.slice_end;
+        SliceDesc sd{0u, 0u, 0u, 0u};
         Acc acc = acc_zero();
+        if (have) {
+            sd = a.slices[s];
+            const uint32_t* __restrict__ cp = a.col + (size_t)sd.off * 64 + lane;
+            const uint4* __restrict__ lop = a.wlo + (size_t)sd.off * 64 + lane;
+            const uint4* __restrict__ hip_ = a.whi + (size_t)sd.off * 64 + lane;
 #pragma unroll 2
-        for (uint32_t k = 0; k < sd.len; ++k) {
-            const uint32_t c = cp[(size_t)k * 64];
-            U256 w = u256_from_planes(lop[(size_t)k * 64], hip_[(size_t)k * 64]);
-            U256 xv = u256_load(a.x + 2 * ((size_t)(c >> COL_SEG_SHIFT) * stride + (c & COL_LOCAL_MASK)));
-            acc_mac(acc, w, xv);
+            for (uint32_t k = 0; k < sd.len; ++k) {
+                const uint32_t c = cp[(size_t)k * 64];
+                U256 w = u256_from_planes(lop[(size_t)k * 64], hip_[(size_t)k * 64]);
+                U256 xv = u256_load(a.x + 2 * ((size_t)(c >> COL_SEG_SHIFT) * stride + (c & COL_LOCAL_MASK)));
+                acc_mac(acc, w, xv);
+            }
         }
+        if (!met) { __syncthreads(); met = true; }     // first pass of every wavefront, with or without a slice
+        if (!have) break;
         const uint32_t sh = slice_log2_lanes(sd.nrows);
         acc_group_sum(acc, 1u << sh);
-        if (s == wd.slice_begin) __syncthreads();
         Acc PD;
 #pragma unroll
         for (int i = 0; i < 17; ++i) PD.v[i] = sh_pd[i];
@@ -486,6 +507,7 @@ __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr(StepArgsFr a) {
             if (dang) dacc = fr_add(dacc, v);
         }
     }
+    if (!has_work) return;                              // past the only barrier
     tot = fr_wave_sum(tot);
     if (dang) dacc = fr_wave_sum(dacc);
 #pragma unroll
@@ -507,56 +529,63 @@ __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr_raw(StepArgsFr a) {
     const int wave = threadIdx.x >> 6;
     const uint32_t stride = a.geo.seg_stride();
     const size_t my_base = (size_t)a.geo.seg * stride;
-    // The first wavefront prepares the dangling mass while the others already walk their first slice;
-    // the workgroup meets once, before the first row is finished (wavefronts without a work item have
-    // left by then and do not count at the barrier).
+    fr_zero_unused_tail(a.y, a.geo, a.n_dslots, WPB_FR * 64);
+    // The first wavefront prepares the dangling mass while the others already walk their first slice.  Every
+    // wavefront of the workgroup stays alive (one without a work item walks no slice) and all of them meet at
+    // ONE barrier, after the first slice's edges and before its rows are finished.
     if (wave == 0) fr_dangling_mass(a.x, a.geo, a.inv_nm1_w, lane, sh_d, sh_pd);
     const uint32_t gw = blockIdx.x * WPB_FR + wave;
-    if (gw >= a.n_work) return;
-    const WorkDesc wd = a.work[gw];
+    const bool has_work = gw < a.n_work;
+    const WorkDesc wd = has_work ? a.work[gw] : WorkDesc{0u, 0u, 0u, 0u};
     const bool dang = (wd.flags & WORK_DANGLING) != 0;
 
     U256 tot = u256_zero(), dacc = u256_zero();
     uint32_t changed = 0;
-    for (uint32_t s = wd.slice_begin; s < wd.slice_end; ++s) {
-        const SliceDesc sd = a.slices[s];
-        const uint32_t* __restrict__ cp = a.col + (size_t)sd.off * 64 + lane;
-        const VT* __restrict__ vp = static_cast<const VT*>(a.val) + (size_t)sd.off * 64 + lane;
+    bool met = false;
+    for (uint32_t s = wd.slice_begin;; ++s) {
+        const bool have = s < wd.slice_end;
+        SliceDesc sd{0u, 0u, 0u, 0u};
         Acc10 acc = acc10_zero();
-        // Batches of U steps with all U gathers in flight together; the last batch may be partial:
-        // its surplus steps re-read the slice's last step with the opinion forced to zero.
-        constexpr int U = 4;
-        const uint32_t len = sd.len;
-        if (len > 0) {
-            const uint32_t last = len - 1;
-            // the records of the next batch are asked for before this batch's gathers, so the two waits overlap
-            uint32_t c[U], v[U];
-#pragma unroll
-            for (int i = 0; i < U; ++i) {
-                const size_t o = (size_t)min((uint32_t)i, last) * 64;
-                c[i] = cp[o];
-                v[i] = (uint32_t)i < len ? (uint32_t)vp[o] : 0u;
-            }
-            for (uint32_t k = 0; k < len; k += U) {
-                uint32_t cn[U], vn[U];
+        if (have) {
+            sd = a.slices[s];
+            const uint32_t* __restrict__ cp = a.col + (size_t)sd.off * 64 + lane;
+            const VT* __restrict__ vp = static_cast<const VT*>(a.val) + (size_t)sd.off * 64 + lane;
+            // Batches of U steps with all U gathers in flight together; the last batch may be partial:
+            // its surplus steps re-read the slice's last step with the opinion forced to zero.
+            constexpr int U = 4;
+            const uint32_t len = sd.len;
+            if (len > 0) {
+                const uint32_t last = len - 1;
+                // the records of the next batch are asked for before this batch's gathers, so the two waits overlap
+                uint32_t c[U], v[U];
 #pragma unroll
                 for (int i = 0; i < U; ++i) {
-                    const size_t o = (size_t)min(k + U + i, last) * 64;
-                    cn[i] = cp[o];
-                    vn[i] = k + U + i < len ? (uint32_t)vp[o] : 0u;
+                    const size_t o = (size_t)min((uint32_t)i, last) * 64;
+                    c[i] = cp[o];
+                    v[i] = (uint32_t)i < len ? (uint32_t)vp[o] : 0u;
                 }
-                U256 xv[U];
+                for (uint32_t k = 0; k < len; k += U) {
+                    uint32_t cn[U], vn[U];
 #pragma unroll
-                for (int i = 0; i < U; ++i) xv[i] = u256_load(a.x + 2 * ((size_t)(c[i] >> COL_SEG_SHIFT) * stride + (c[i] & COL_LOCAL_MASK)));
+                    for (int i = 0; i < U; ++i) {
+                        const size_t o = (size_t)min(k + U + i, last) * 64;
+                        cn[i] = cp[o];
+                        vn[i] = k + U + i < len ? (uint32_t)vp[o] : 0u;
+                    }
+                    U256 xv[U];
 #pragma unroll
-                for (int i = 0; i < U; ++i) acc10_mac_u32(acc, xv[i], v[i]);
+                    for (int i = 0; i < U; ++i) xv[i] = u256_load(a.x + 2 * ((size_t)(c[i] >> COL_SEG_SHIFT) * stride + (c[i] & COL_LOCAL_MASK)));
 #pragma unroll
-                for (int i = 0; i < U; ++i) { c[i] = cn[i]; v[i] = vn[i]; }
+                    for (int i = 0; i < U; ++i) acc10_mac_u32(acc, xv[i], v[i]);
+#pragma unroll
+                    for (int i = 0; i < U; ++i) { c[i] = cn[i]; v[i] = vn[i]; }
+                }
             }
         }
+        if (!met) { __syncthreads(); met = true; }     // first pass of every wavefront, with or without a slice
+        if (!have) break;
         const uint32_t sh = slice_log2_lanes(sd.nrows);
         acc10_group_sum(acc, 1u << sh);
-        if (s == wd.slice_begin) __syncthreads();
         Acc full = acc_from_acc10(acc);
         const uint32_t row = sd.row0 + ((uint32_t)lane >> sh);
         const bool live = ((uint32_t)lane & ((1u << sh) - 1)) == 0 && ((uint32_t)lane >> sh) < slice_rows(sd.nrows);
@@ -580,6 +609,7 @@ __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr_raw(StepArgsFr a) {
             if (dang) dacc = fr_add(dacc, v);
         }
     }
+    if (!has_work) return;                              // past the only barrier
     tot = fr_wave_sum(tot);
     if (dang) dacc = fr_wave_sum(dacc);
 #pragma unroll
@@ -646,6 +676,8 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     const uint32_t stride = a.geo.seg_stride();
     const size_t my_base = (size_t)a.geo.seg * stride;
     for (uint32_t i = threadIdx.x; i < 8 * RB; i += 1024) colsum_l[i] = 0;
+    // partial-sum slots no workgroup writes: zero, whatever the caller's buffer held (see fr_zero_unused_tail)
+    fr_zero_unused_tail(a.y, a.geo, a.geo.fr_dblocks, 1024);
     __syncthreads();
     // the first wavefront prepares the dangling term while the others already sweep; the workgroup next meets at
     // the sweep's own barriers, and the term is read after the barrier that ends the sweep
@@ -932,6 +964,7 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     g->n = h.n; g->n_valid = h.n_valid; g->nnz = h.nnz; g->nnz_local = h.nnz_local;
     g->geo = h.geo; g->n_steps = h.n_steps; g->n_slices = (uint32_t)h.slices.size();
     g->n_work = (uint32_t)h.work.size(); g->n_dangling_local = h.n_dangling_local;
+    for (const WorkDesc& w : h.work) if (w.flags & WORK_DANGLING) g->n_dslots = std::max(g->n_dslots, w.dslot + 1);
     g->fr_blocked = h.geo.fr_blocks != 0 && !h.fb_ptr.empty();
     g->n_fr_parts = g->fr_blocked ? h.geo.fr_blocks : g->n_work;
     g->pos_of_ext = h.pos_of_ext;
@@ -1137,8 +1170,9 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
     size_t ring = (size_t)(iteration % STATS_RING) * n_work;
     a.sum_part = d_frsum_part + 2 * ring; a.chg_part = d_chg_part + ring;
     a.geo = geo; a.n_work = n_work; a.inv_nm1_w = to_u256(inv_nm1_w); a.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u;
-    if (n_work == 0) return ET_OK;
-    const unsigned grid = (n_work + WPB_FR - 1) / WPB_FR;
+    a.n_dslots = n_dslots;
+    // a share without rows still launches one workgroup: it owns the partial-sum tail of its segment
+    const unsigned grid = std::max(1u, (n_work + WPB_FR - 1) / WPB_FR);
     if (!raw) hipLaunchKernelGGL(k_step_fr, dim3(grid), dim3(WPB_FR * 64), 0, st, a);
     else if (val_bytes == 1) hipLaunchKernelGGL(k_step_fr_raw<uint8_t>, dim3(grid), dim3(WPB_FR * 64), 0, st, a);
     else hipLaunchKernelGGL(k_step_fr_raw<uint32_t>, dim3(grid), dim3(WPB_FR * 64), 0, st, a);

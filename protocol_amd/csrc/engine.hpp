@@ -21,6 +21,7 @@ struct DeviceGraph {
     uint32_t n = 0, n_valid = 0;
     uint64_t nnz = 0, nnz_local = 0, n_steps = 0;
     uint32_t n_slices = 0, n_work = 0, n_dangling_local = 0;
+    uint32_t n_dslots = 0;            // partial-sum slots the row-per-lane exact kernels write (their dangling work items)
     Geometry geo{};
     size_t vec_len = 0;
     uint64_t device_bytes = 0;

@@ -76,6 +76,10 @@ class Graph:
         except Exception:
             pass
 
+    def exact_kernel_name(self):
+        """Which kernel iterates the exact variant on this graph (for reports)."""
+        return "k_step_fr_blocked" if int(self.info.exact_sweep_blocks) != 0 else "k_step_fr_raw"
+
     # whole converge, host in / host out ------------------------------------------------------
     def converge_fr(self, num_iterations=20, initial=1000):
         out = np.zeros((self.n, 32), dtype=np.uint8)

@@ -7,9 +7,10 @@ all-gather of the segments then gives every rank the whole new vector and every 
 That all-gather is the only collective on the path.
 
 Segments are dealt 64 rows at a time round-robin in degree order, so every rank gets the same number
-of rows and a near-identical degree mix; results do not depend on the number of ranks (the Fr
-variant is exact integer arithmetic; the f64 variant sums each row on one rank in a fixed order and
-combines partial sums in a fixed order).
+of rows and a near-identical degree mix.  The Fr variant is exact integer arithmetic: its result does
+not depend on the number of ranks, bit for bit.  The f64 variant adds a row's terms in whatever order
+the hardware serves its LDS atomics, so its last bits vary from run to run and with the layout (the
+difference stays within the usual summation error, far below the 1e-9 the variant is held to).
 """
 import numpy as np
 import torch
@@ -145,8 +146,15 @@ class ShardedGraph:
         return self.result_f64()
 
     def _sum_mod_r(self, mine):
+        """Field sum over the ranks' partial sums: one gather of 32 bytes per rank."""
         if self.world == 1:
             return mine % R_MODULUS
-        parts = [None] * self.world
-        dist.all_gather_object(parts, int(mine), group=self.group)
-        return sum(parts) % R_MODULUS
+        dev = self.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        words = np.frombuffer(int(mine % R_MODULUS).to_bytes(32, "little"), dtype=np.int64).copy()
+        t = torch.from_numpy(words).to(dev)
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t, group=self.group)
+        total = 0
+        for p in parts:
+            total += int.from_bytes(p.cpu().numpy().tobytes(), "little")
+        return total % R_MODULUS
