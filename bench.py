@@ -8,14 +8,21 @@ region starts.
 
   N = 1   : 1 048 576 peers, 16 777 216 attestations, power-law out-degree (the configuration the
             metric is quoted on); f64 and Fr-exact variants are both timed, `value` is the f64 one.
+            The same line carries the other single-GPU configurations under "configs": the 64K-peer
+            graph, the batch of 4096 small sets and the latency of one converge of the reference's
+            own small sets beside the dense CPU restatement.
   N > 1   : 16 777 216 peers, 268 435 456 attestations row-sharded over the N GPUs, one all-gather
-            of the trust vector per iteration (torch.distributed, backend nccl = RCCL).
+            of the trust vector per iteration (torch.distributed, backend nccl = RCCL).  Started
+            without a launcher, the script starts its own N ranks (before it touches the GPU).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,12 +42,11 @@ WORKLOADS = {
 C5_SETS, C5_SLOTS = 4096, 256   # batched small sets (ZK witness generation), split over the GPUs without communication
 
 
-
 def algorithmic_bytes(variant, nnz, rows):
     """Bytes one iteration launch must move when every array is touched once.
     f64: CSR of C^T with pre-normalised weights, nnz*(8+4) + rows*(4+8+8) -- the per-edge figure the
-    metric's roofline is quoted on; the kernel's own edge records are smaller (7 B: source, slot,
-    opinion byte).
+    metric's roofline is quoted on; the kernel's own edge records are smaller (5 B: slot + source
+    offset, opinion byte).
     Fr: the kernel iterates the factored form (raw opinion + source per edge, s*inv(sum) per row),
     whose compulsory traffic is nnz*(4+4) + rows*(4+32*3); the weighted CSR form would be
     nnz*36 + rows*68 and is reported beside it."""
@@ -49,7 +55,50 @@ def algorithmic_bytes(variant, nnz, rows):
     return nnz * 8 + rows * 100
 
 
-def bench_small_sets(args, world, rank, device, red):
+def kernel_sources_sha():
+    """Identifies the kernels a counter record was taken on: hash of the sources the library is built from."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "protocol_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".cpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def counter_record(wl, kernel, launch_us):
+    """Fabric traffic per launch from the PMC passes of this same workload (tools/pmc_passes.sh +
+    tools/traffic_record.py; rocprofv3 cannot be nested inside the bench).  The record counts only for the
+    kernel it names, built from the sources it was taken on, and only while the launch time measured now is
+    within 10 % of the one measured then; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f)
+    k = rec.get("kernels", {}).get(kernel)
+    if not k or rec.get("workload") != wl or rec.get("csrc_sha") != kernel_sources_sha():
+        return None
+    if abs(k.get("launch_us", 0.0) - launch_us) > 0.10 * launch_us:
+        return None
+    return k
+
+
+def spawn_ranks(n):
+    """--gpus N without a launcher: start N ranks with torch.distributed.run as a child process.  The parent
+    has not touched the GPU, and it waits for the child instead of replacing itself."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def bench_small_sets(args, world, rank, device, red, steps, warmup, with_cpu):
     """4096 independent 256-slot sets (240-256 members each, ~5 % all-zero rows), 20 iterations, exact:
     every rank converges its own 4096 / world sets, one workgroup per set, no communication.
     Edge-iterations count the dense edges the reference iterates over: n_valid * (n_valid - 1) per set."""
@@ -58,17 +107,19 @@ def bench_small_sets(args, world, rank, device, red):
     import torch.distributed as dist
     import protocol_amd as pa
 
-    C5_SETS, C5_SLOTS = args.c5_sets, args.c5_slots      # defaults: the 4096 x 256 configuration
-    rng = np.random.default_rng(args.seed + 5)
-    values = rng.integers(1, 256, (C5_SETS, C5_SLOTS, C5_SLOTS), dtype=np.uint32)
-    member = np.ones((C5_SETS, C5_SLOTS), dtype=np.uint8)
-    n_members = rng.integers(C5_SLOTS - C5_SLOTS // 16, C5_SLOTS + 1, C5_SETS)
-    for s in range(C5_SETS):
-        member[s, n_members[s]:] = 0
-    values[rng.random((C5_SETS, C5_SLOTS)) < 0.05] = 0
-    lo, hi = C5_SETS * rank // world, C5_SETS * (rank + 1) // world
+    sets, slots = args.c5_sets, args.c5_slots      # defaults: the 4096 x 256 configuration
+    lo, hi = sets * rank // world, sets * (rank + 1) // world
+    # every rank draws only its own sets, each from a seed of its own
+    values = np.empty((hi - lo, slots, slots), dtype=np.uint32)
+    member = np.ones((hi - lo, slots), dtype=np.uint8)
+    for s in range(lo, hi):
+        rng = np.random.default_rng([args.seed + 5, s])
+        v = rng.integers(1, 256, (slots, slots), dtype=np.uint32)
+        v[rng.random(slots) < 0.05] = 0
+        values[s - lo] = v
+        member[s - lo, int(rng.integers(slots - slots // 16, slots + 1)):] = 0
     t0 = time.time()
-    batch = pa.Batch(values[lo:hi], member[lo:hi])
+    batch = pa.Batch(values, member)
     t_create = time.time() - t0
     st = torch.cuda.current_stream(device).cuda_stream
 
@@ -78,11 +129,11 @@ def bench_small_sets(args, world, rank, device, red):
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         batch.run_fr(NUM_ITER, INITIAL, st)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         batch.run_fr(NUM_ITER, INITIAL, st)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -96,62 +147,79 @@ def bench_small_sets(args, world, rank, device, red):
     out, status = batch.result_fr(st)
     ok = bool((status == 0).all())
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import c_oracle
         sample = [0, (hi - lo) // 2, hi - lo - 1]
-        t0 = time.perf_counter()
         cpu_edges = 0
         for s in sample:
-            rows = [[int(v) for v in values[lo + s, i]] for i in range(C5_SLOTS)]
+            rows = [[int(v) for v in values[s, i]] for i in range(slots)]
             t1 = time.perf_counter()
-            rc, exp, _ = c_oracle.dense_converge_fr(C5_SLOTS, NUM_ITER, INITIAL, member[lo + s], member[lo + s], rows)
+            rc, exp, _ = c_oracle.dense_converge_fr(slots, NUM_ITER, INITIAL, member[s], member[s], rows)
             secs = time.perf_counter() - t1
             ok = ok and rc == 0 and pa.fr_ints_from_bytes(out[s]) == exp
-            nv = int(member[lo + s].sum())
+            nv = int(member[s].sum())
             cpu_edges += nv * (nv - 1) * NUM_ITER / secs
         cpu = {"value": cpu_edges / len(sample), "unit": "edge-iterations/s", "cores": 1, "kind": "port",
-               "sample": "3 of the %d sets, dense loop nest of the reference restated in C, one thread" % C5_SETS}
-    if rank == 0:
-        print(json.dumps({
-            "metric": "edge-iterations/sec", "value": edges * NUM_ITER * args.steps / elapsed, "unit": "edge-iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "fr254", "data": "synthetic",
-            "config": {"workload": "c5: %d independent sets x %d slots, %d iterations, exact; sets split over the GPUs" % (C5_SETS, C5_SLOTS, NUM_ITER),
-                       "sets": C5_SETS, "slots": C5_SLOTS, "iterations": NUM_ITER, "parallelism": "sets split x%d" % world,
-                       "seed": args.seed},
-            "sets_per_s": C5_SETS * args.steps / elapsed,
-            # the dense product runs as byte-limb i8 MFMA tiles (32 limbs x 256 sources x 256 columns per set and
-            # iteration, plus a third as many against a matrix of ones); i8 dense peak = 2 x bf16.  The launch is
-            # bound by the per-element field arithmetic on the vector ALUs, not by the matrix cores.
-            "roofline": {"bound": "mfma", "achieved": C5_SETS * NUM_ITER * args.steps * 2.0 * 32 * C5_SLOTS * C5_SLOTS / elapsed / 1e12,
-                         "peak": 5000.0, "unit": "TFLOP/s",
-                         "frac": C5_SETS * NUM_ITER * args.steps * 2.0 * 32 * C5_SLOTS * C5_SLOTS / elapsed / 1e12 / 5000.0,
-                         "traffic": None,
-                         "kernel": "k_batch_fr_mfma_packed" if C5_SLOTS <= 32 else ("k_batch_fr_mfma" if C5_SLOTS <= 256 else "k_batch_fr_mfma_stream"),
-                         "note": "integer ops of the byte-limb product; the kernel's bound is 32-bit VALU field arithmetic"},
-            "cpu_baseline": cpu,
-            "checks": {"all_status_ok": ok, "sampled_sets_bit_exact": ok},
-            "setup_s": {"create": t_create},
-        }), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+               "sample": "3 of the %d sets, dense loop nest of the reference restated in C, one thread" % sets}
+    ops = sets * NUM_ITER * steps * 2.0 * 32 * slots * slots / elapsed / 1e12
+    return {
+        "metric": "edge-iterations/sec", "value": edges * NUM_ITER * steps / elapsed, "unit": "edge-iterations/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "fr254", "data": "synthetic",
+        "config": {"workload": "c5: %d independent sets x %d slots, %d iterations, exact; sets split over the GPUs" % (sets, slots, NUM_ITER),
+                   "sets": sets, "slots": slots, "iterations": NUM_ITER, "parallelism": "sets split x%d" % world,
+                   "seed": args.seed},
+        "sets_per_s": sets * steps / elapsed,
+        # the dense product runs as byte-limb i8 MFMA tiles (32 limbs x 256 sources x 256 columns per set and
+        # iteration, plus a third as many against a matrix of ones); i8 dense peak = 2 x bf16.  The launch is
+        # bound by the per-element field arithmetic on the vector ALUs, not by the matrix cores.
+        "roofline": {"bound": "mfma", "achieved": ops, "peak": 5000.0, "unit": "TFLOP/s", "frac": ops / 5000.0,
+                     "traffic": None,
+                     "kernel": "k_batch_fr_mfma_packed" if slots <= 32 else ("k_batch_fr_mfma" if slots <= 256 else "k_batch_fr_mfma_stream"),
+                     "note": "integer ops of the byte-limb product; the kernel's bound is 32-bit VALU field arithmetic"},
+        "cpu_baseline": cpu,
+        "checks": {"all_status_ok": ok, "sampled_sets_bit_exact": ok},
+        "setup_s": {"create": t_create},
+    }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "c4", "c5"])
-    ap.add_argument("--variant", default="both", choices=["both", "f64", "fr"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--c5-sets", type=int, default=C5_SETS, help="small-set workload: number of sets")
-    ap.add_argument("--c5-slots", type=int, default=C5_SLOTS, help="small-set workload: slots per set (<= 1024)")
-    args = ap.parse_args()
+def bench_set_latency(args):
+    """The reference's own configuration: ONE converge of one small set through the set API
+    (EigenTrustSet::converge, native.rs:286-337), wall time per call including every host step, for the
+    production size (4 slots, circuits/mod.rs:39), the reference's test sizes (12 slots / 10 iterations,
+    native.rs:410-413) and a 256-slot set; beside it the dense loop nest restated in C on one thread."""
+    import numpy as np
+    import protocol_amd as pa
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    rows = []
+    for n, iters in ((4, 20), (12, 10), (256, 20)):
+        rng = np.random.default_rng(args.seed + n)
+        vals = rng.integers(1, 256, (n, n), dtype=np.uint32)
+        s = pa.EigenTrustSet(42, n, iters, INITIAL)
+        for i in range(n):
+            s.add_member(1000 + i)
+        about = np.arange(n, dtype=np.uint32)
+        for i in range(n):
+            s.update_op_u32(i, about, vals[i])
+        first = time.perf_counter()
+        got = s.converge()
+        first = time.perf_counter() - first
+        reps = 200 if n <= 12 else 50
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            s.converge()
+        gpu = (time.perf_counter() - t0) / reps
+        ones = np.ones(n, dtype=np.uint8)
+        rc, exp, secs = c_oracle.dense_converge_fr(n, iters, INITIAL, ones, ones, [[int(v) for v in r] for r in vals])
+        rows.append({"slots": n, "iterations": iters, "gpu_us_per_converge": gpu * 1e6, "gpu_first_call_us": first * 1e6,
+                     "cpu_port_us_per_converge": secs * 1e6, "bit_exact": bool(rc == 0 and got == exp)})
+    return {"workload": "c1: one EigenTrustSet::converge through the set API, wall time per call", "sets": rows,
+            "cpu_baseline": {"kind": "port", "cores": 1, "sample": "dense loop nest of native.rs:286-337 restated in C, one call"}}
 
+
+def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -159,34 +227,7 @@ def main():
     import protocol_amd as pa
     from protocol_amd.sharded import ShardedGraph
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
-    # rehearsal knobs (one-GPU box): ET_BENCH_DEVICE pins every rank to one card, ET_BENCH_BACKEND=gloo stages the
-    # exchange through host memory; the driver's multi-GPU runs use neither
-    if "ET_BENCH_DEVICE" in os.environ:
-        local_rank = int(os.environ["ET_BENCH_DEVICE"])
-    backend = os.environ.get("ET_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
-
-    wl = args.workload
-    if wl == "auto":
-        wl = "c3" if world == 1 else "c4"
-    # small reductions travel on the device with nccl, on the host in a gloo rehearsal
-    red = device if backend == "nccl" else torch.device("cpu")
-    if wl == "c5":
-        return bench_small_sets(args, world, rank, device, red)
     kind, n, target_edges, desc = WORKLOADS[wl]
-
     t0 = time.time()
     frm, to, val = pa.synth_graph(kind, n, target_edges, seed=args.seed, value_max=255)
     t_gen = time.time() - t0
@@ -205,26 +246,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    # HBM/fabric traffic per launch measured with PMC counters in a separate profiling run of this
-    # same workload (rocprofv3 cannot be nested inside the bench); null when no such record exists
-    traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-    if world == 1 and os.path.exists(tpath):
-        with open(tpath) as f:
-            rec = json.load(f)
-        if rec.get("workload") == wl:
-            traffic = {k: v["traffic_bytes"] for k, v in rec["kernels"].items()}
-            # share of the vector-ALU issue slots the exact kernel used in that profile: wave-instructions x 4 cycles
-            # (a SIMD issues one full-rate wave64 instruction per 4 cycles; the 64-bit multiply-adds take longer, so
-            # this is a lower bound) over 1024 SIMDs x the cycles of the launch
-            fr_rec = rec["kernels"].get("k_step_fr", {})
-            traffic["fr_kernel"] = fr_rec.get("kernel")
-            if "SQ_INSTS_VALU" in fr_rec:
-                traffic["fr_valu_issue_frac"] = fr_rec["SQ_INSTS_VALU"] * 4.0 / (1024 * fr_rec["GRBM_GUI_ACTIVE"] / 8.0)
-
     # what a plain device-to-device copy reaches on this card (read + write bytes), beside the 8 TB/s peak
     copy_gbs = None
-    if world == 1:
+    if world == 1 and wl == "c3":
         src = torch.empty(1 << 27, dtype=torch.float64, device=device).fill_(1.0)
         dst = torch.empty_like(src)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -237,12 +261,7 @@ def main():
         copy_gbs = 5 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
 
-    # the exact variant runs as a blocked sweep for one share of 512K to 2M rows of byte opinions, else row per lane
-    fr_blocked = int(info.exact_sweep_blocks) != 0
-    fr_kernel = "k_step_fr_blocked" if fr_blocked else "k_step_fr_raw<u8>"
-    if traffic.get("fr_kernel") not in (None, fr_kernel):   # the counters on record are another kernel's
-        traffic.pop("k_step_fr", None)
-        traffic.pop("fr_valu_issue_frac", None)
+    fr_kernel = sg.graph.exact_kernel_name()
     results = {}
     for variant in (["f64", "fr"] if args.variant == "both" else [args.variant]):
         if variant == "f64":
@@ -251,12 +270,12 @@ def main():
         else:
             def run(rec):
                 return sg.run_fr(NUM_ITER, INITIAL, record=rec)
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             run(False)
         barrier()
         sg.graph.event_times()  # empty the event ring
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             run(True)
         barrier()
         elapsed = time.perf_counter() - t0
@@ -272,20 +291,27 @@ def main():
         rows_local = int(info.n_valid) // world
         alg = algorithmic_bytes(variant, int(info.nnz_local), rows_local)
         achieved = alg / launch_s / 1e9
+        kernel = "k_step_f64_blocked<u8>" if variant == "f64" else fr_kernel
+        rec = counter_record(wl, kernel, launch_s * 1e6) if world == 1 else None
         results[variant] = {
-            "value": nnz * NUM_ITER * args.steps / elapsed,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "value": nnz * NUM_ITER * steps / elapsed,
+            "ms_per_step": elapsed / steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic.get("k_step_f64" if variant == "f64" else "k_step_fr"),
-                         "kernel": "k_step_f64_blocked<u8>" if variant == "f64" else fr_kernel,
+                         "traffic": rec["traffic_bytes"] if rec else None,
+                         "kernel": kernel,
                          "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": alg,
                          "device_copy_GBs": copy_gbs},
         }
         if variant == "fr":
-            results[variant]["roofline"]["valu_issue_frac"] = traffic.get("fr_valu_issue_frac")
-            results[variant]["roofline"]["form"] = "factored (raw opinions, pre-scaled vector)"
-            results[variant]["roofline"]["weighted_csr_bytes_per_launch"] = int(info.nnz_local) * 36 + rows_local * 68
+            r = results[variant]["roofline"]
+            # share of the vector-ALU issue slots the exact kernel used in the counter passes: wave-instructions x 4
+            # cycles (a SIMD issues one full-rate wave64 instruction per 4 cycles; the 64-bit multiply-adds take
+            # longer, so this is a lower bound) over 1024 SIMDs x the cycles of the launch
+            r["valu_issue_frac"] = (rec["SQ_INSTS_VALU"] * 4.0 / (1024 * rec["GRBM_GUI_ACTIVE"] / 8.0)
+                                    if rec and "SQ_INSTS_VALU" in rec and "GRBM_GUI_ACTIVE" in rec else None)
+            r["form"] = "factored (raw opinions, pre-scaled vector)"
+            r["weighted_csr_bytes_per_launch"] = int(info.nnz_local) * 36 + rows_local * 68
 
     # parity of the timed configuration: conservation of the score sum (native.rs:331-334)
     checks = {}
@@ -304,7 +330,7 @@ def main():
         checks["f64_residual_l1"] = res
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and with_cpu:
         # the CPU checker (a port: the reference is Rust and cannot be built in this image),
         # timed on this box's host cores over the same graph and the same 20 iterations
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -336,23 +362,94 @@ def main():
                                                              initial=INITIAL, n_threads=1)
             cpu["fr_value_1_thread"] = cnnz * 4 / secs
 
+    head = results.get("f64") or results["fr"]
+    line = {
+        "metric": "edge-iterations/sec", "value": head["value"], "unit": "edge-iterations/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": head["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
+        "dtype": "f64" if "f64" in results else "fr254", "data": "synthetic",
+        "config": {"workload": "%s: %s; %d iterations per step; byte opinions kept raw in the edge records" % (wl, desc, NUM_ITER),
+                   "peers": n, "edges": nnz, "iterations": NUM_ITER, "parallelism": "rows sharded x%d" % world,
+                   "seed": args.seed},
+        "roofline": head["roofline"],
+        "cpu_baseline": cpu,
+        "checks": checks,
+        "setup_s": {"generate": t_gen, "build_and_upload": t_build},
+    }
+    if "fr" in results and "f64" in results:
+        line["fr_exact"] = dict(results["fr"], dtype="fr254 (8x32-bit limbs)", unit="edge-iterations/s")
+    sg.graph.close()
+    return line
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="auto", choices=["auto", "c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--variant", default="both", choices=["both", "f64", "fr"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1, workload auto: only the 1M-peer graph, not the other configurations")
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--c5-sets", type=int, default=C5_SETS, help="small-set workload: number of sets")
+    ap.add_argument("--c5-slots", type=int, default=C5_SLOTS, help="small-set workload: slots per set (<= 1024)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))       # nothing above touched the GPU
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (one-GPU box): ET_BENCH_BACKEND=gloo stages the exchange through host memory and lets several
+    # ranks share a card (RCCL refuses two ranks of one communicator on one GPU); ET_BENCH_DEVICE pins every rank to
+    # one card.  The driver's multi-GPU runs use neither: one rank per GPU over RCCL.
+    backend = os.environ.get("ET_BENCH_BACKEND", "nccl")
+    if "ET_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["ET_BENCH_DEVICE"])
+    elif backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())   # counting devices does not initialise the GPU
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    # small reductions travel on the device with nccl, on the host in a gloo rehearsal
+    red = device if backend == "nccl" else torch.device("cpu")
+    with_cpu = not args.no_cpu_baseline
+
+    wl = args.workload
+    if wl == "auto":
+        wl = "c3" if world == 1 else "c4"
+    if wl == "c1":
+        line = {"metric": "us per converge", "unit": "us", "higher_is_better": False, "n_gpus": 1, "data": "synthetic",
+                "dtype": "fr254", "config": bench_set_latency(args)}
+    elif wl == "c5":
+        line = bench_small_sets(args, world, rank, device, red, args.steps, args.warmup, with_cpu)
+    else:
+        line = bench_graph(args, wl, world, rank, device, red, args.steps, args.warmup, with_cpu)
+        if args.workload == "auto" and world == 1 and not args.no_extras:
+            # the other single-GPU configurations, briefly, inside the same line
+            saved = args.variant
+            c2 = bench_graph(args, "c2", 1, 0, device, red, max(3, args.steps // 2), 2, with_cpu)
+            args.variant = saved
+            c5 = bench_small_sets(args, 1, 0, device, red, max(3, args.steps // 2), 2, with_cpu)
+            keep = ("value", "unit", "ms_per_step", "roofline", "fr_exact", "cpu_baseline", "checks", "sets_per_s", "dtype")
+            line["configs"] = {
+                "c2": dict({k: c2[k] for k in keep if k in c2}, workload=c2["config"]["workload"]),
+                "c5": dict({k: c5[k] for k in keep if k in c5}, workload=c5["config"]["workload"]),
+                "c1": bench_set_latency(args),
+            }
     if rank == 0:
-        head = results.get("f64") or results["fr"]
-        line = {
-            "metric": "edge-iterations/sec", "value": head["value"], "unit": "edge-iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
-            "dtype": "f64" if "f64" in results else "fr254", "data": "synthetic",
-            "config": {"workload": "%s: %s; %d iterations per step; byte opinions kept raw in the edge records" % (wl, desc, NUM_ITER),
-                       "peers": n, "edges": nnz, "iterations": NUM_ITER, "parallelism": "rows sharded x%d" % world,
-                       "seed": args.seed},
-            "roofline": head["roofline"],
-            "cpu_baseline": cpu,
-            "checks": checks,
-            "setup_s": {"generate": t_gen, "build_and_upload": t_build},
-        }
-        if "fr" in results and "f64" in results:
-            line["fr_exact"] = dict(results["fr"], dtype="fr254 (8x32-bit limbs)", unit="edge-iterations/s")
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
