@@ -238,6 +238,9 @@ extern "C" {
     pub fn et_batch_edges(b: *const et_batch, edges: *mut u64) -> c_int;
     pub fn et_batch_converge_fr(n_sets: u32, n: u32, member: *const u8, values: *const u32, num_iterations: u32,
                                 initial_lo: u64, initial_hi: u64, out: *mut et_fr, status: *mut i32) -> c_int;
+    /// The same without any device allocation (the batch lives in the library's resident scratch array).
+    pub fn et_batch_converge_fr_noalloc(n_sets: u32, n: u32, member: *const u8, values: *const u32, num_iterations: u32,
+                                        initial_lo: u64, initial_hi: u64, out: *mut et_fr, status: *mut i32) -> c_int;
 
     pub fn et_synth_graph(kind: u32, n: u32, target_edges: u64, seed: u64, value_max: u32, n_edges: *mut u64,
                           from: *mut u32, to: *mut u32, value: *mut u32) -> c_int;

@@ -282,6 +282,21 @@ int et_batch_converge_fr(uint32_t n_sets, uint32_t n, const uint8_t *member, con
                          uint32_t num_iterations, uint64_t initial_lo, uint64_t initial_hi,
                          et_fr *out, int32_t *status);
 
+/* et_batch_converge_fr for callers that cannot allocate device memory (tight serving loops, harnesses
+ * that forbid hipMalloc): same arguments, same results bit for bit, but no hipMalloc / hipFree -- the
+ * batch's device arrays are carved out of one array of ET_NOALLOC_SCRATCH_BYTES that is part of the
+ * library's code object (each GPU the library runs on holds its copy until the process ends).  This
+ * entry point has no counterpart in the reference.  It runs on the current device, is synchronous,
+ * and returns ET_E_BUFFER_TOO_SMALL when the batch needs more than the array holds (byte opinions:
+ * about n_sets * (roundup(n, 64)^2 + 72 n) bytes; larger opinions 4 n^2 + 72 n per set).  Every call
+ * on a GPU uses that GPU's one array: calls from several host threads are serialised by a lock inside
+ * the library, and nothing else may be using the array's memory (there is no other way to reach it). */
+#define ET_NOALLOC_SCRATCH_BYTES (4u << 20)
+#define ET_NOALLOC_MAX_DEVICES 64
+int et_batch_converge_fr_noalloc(uint32_t n_sets, uint32_t n, const uint8_t *member,
+                                 const uint32_t *values, uint32_t num_iterations, uint64_t initial_lo,
+                                 uint64_t initial_hi, et_fr *out, int32_t *status);
+
 /* ------------------------------------------------------------------------------------------
  * Deterministic synthetic attestation lists (benchmarks and parity tests use the same inputs).
  * kind: 2 = uniform out-degree, 3 = power-law out-degree with preferential targets and a share of

@@ -142,6 +142,7 @@ PROTOTYPES = {
     "et_batch_result_fr": (i32, [vp, vp, vp, vp]),
     "et_batch_edges": (i32, [vp, P(u64)]),
     "et_batch_converge_fr": (i32, [u32, u32, vp, vp, u32, u64, u64, vp, vp]),
+    "et_batch_converge_fr_noalloc": (i32, [u32, u32, vp, vp, u32, u64, u64, vp, vp]),
     "et_synth_graph": (i32, [u32, u32, u64, u64, u32, P(u64), vp, vp, vp]),
     "et_dev_fr_mul": (i32, [u32, vp, vp, vp]),
     "et_ratio_decompose": (i32, [vp, C.c_size_t, vp, C.c_size_t, u32, u32, vp, vp]),

@@ -20,6 +20,7 @@
 #include <atomic>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -678,12 +679,40 @@ struct DeviceBatch {
     uint4* d_out = nullptr;
     int32_t* d_status = nullptr;
     uint64_t edges = 0;   // sum over sets of n_valid * (n_valid - 1): dense edge count of the reference
+    bool owns = true;     // false: the arrays are carved out of the library's resident scratch array, nothing to free
     ~DeviceBatch() {
+        if (!owns) return;
         if (device >= 0) (void)hipSetDevice(device);
         void* p[] = {d_vals, d_member, d_dangling, d_scale, d_inw, d_pre, d_out, d_status, d_colsum};
         for (void* q : p) if (q) (void)hipFree(q);
     }
 };
+
+// Where a batch's device arrays come from: hipMalloc (arena == nullptr), or consecutive 256-byte aligned pieces of
+// a region that already exists (the entry point that allocates nothing).
+struct Arena {
+    uint8_t* base = nullptr;
+    size_t cap = 0, used = 0;
+};
+static int batch_dev_alloc(Arena* arena, void** p, size_t bytes) {
+    if (!arena) {
+        HIP_TRY_B(hipMalloc(p, bytes ? bytes : 1));
+        return ET_OK;
+    }
+    const size_t need = (bytes + 255) / 256 * 256;
+    if (arena->used + need > arena->cap) {
+        set_error("batch needs more than the " + std::to_string(arena->cap) + " bytes of resident scratch memory");
+        return ET_E_BUFFER_TOO_SMALL;
+    }
+    *p = arena->base + arena->used;
+    arena->used += need;
+    return ET_OK;
+}
+#define BATCH_ALLOC(ptr, bytes)                                                        \
+    do {                                                                               \
+        int _rc = batch_dev_alloc(arena, (void**)&(ptr), (bytes));                     \
+        if (_rc) return _rc;                                                           \
+    } while (0)
 
 template <typename F>
 static void parallel_sets(uint32_t n, F f) {
@@ -717,9 +746,8 @@ struct et_batch {
     DeviceBatch b;
 };
 
-extern "C" {
-
-int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const uint32_t* values, int device, et_batch** out) {
+static int batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const uint32_t* values, int device, Arena* arena,
+                        et_batch** out) {
     if (!out || !values || n_sets == 0 || n == 0) return ET_E_INVALID_ARG;
     if (n > 1024) { set_error("a batched set holds at most 1024 slots"); return ET_E_UNSUPPORTED; }
     int ndev = 0;
@@ -758,6 +786,7 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
     std::unique_ptr<et_batch> h(new et_batch());
     DeviceBatch& b = h->b;
     b.device = device; b.n_sets = n_sets; b.n = n;
+    b.owns = arena == nullptr;
     for (uint64_t e : edges) b.edges += e;
     // opinions about empty slots or from empty slots never count: zero them once here so the
     // kernel only has to skip the diagonal
@@ -811,9 +840,9 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
                         }
             }
         });
-        HIP_TRY_B(hipMalloc(&b.d_vals, vt_bytes));
+        BATCH_ALLOC(b.d_vals, vt_bytes);
         HIP_TRY_B(hipMemcpy(b.d_vals, vt.get(), vt_bytes, hipMemcpyHostToDevice));
-        HIP_TRY_B(hipMalloc((void**)&b.d_colsum, colsum.size() * 4));
+        BATCH_ALLOC(b.d_colsum, colsum.size() * 4);
         HIP_TRY_B(hipMemcpy(b.d_colsum, colsum.data(), colsum.size() * 4, hipMemcpyHostToDevice));
     } else {
         // the vector kernels multiply the factor with a canonical score and divide by 2^288 twice per iteration
@@ -832,7 +861,7 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
             uint8_t* o = v8.data() + (size_t)s * n * n;
             for (uint32_t i = 0; i < n; ++i) for (uint32_t j = 0; j < n; ++j) o[(size_t)i * n + j] = (m[i] && m[j] && i != j) ? (uint8_t)v[(size_t)i * n + j] : 0;
         });
-        HIP_TRY_B(hipMalloc(&b.d_vals, cells));
+        BATCH_ALLOC(b.d_vals, cells);
         HIP_TRY_B(hipMemcpy(b.d_vals, v8.data(), cells, hipMemcpyHostToDevice));
     } else if (!b.mfma) {
         std::vector<uint32_t> v32(cells);
@@ -842,16 +871,16 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
             uint32_t* o = v32.data() + (size_t)s * n * n;
             for (uint32_t i = 0; i < n; ++i) for (uint32_t j = 0; j < n; ++j) o[(size_t)i * n + j] = (m[i] && m[j] && i != j) ? v[(size_t)i * n + j] : 0;
         });
-        HIP_TRY_B(hipMalloc(&b.d_vals, cells * 4));
+        BATCH_ALLOC(b.d_vals, cells * 4);
         HIP_TRY_B(hipMemcpy(b.d_vals, v32.data(), cells * 4, hipMemcpyHostToDevice));
     }
-    HIP_TRY_B(hipMalloc((void**)&b.d_member, rows));
-    HIP_TRY_B(hipMalloc((void**)&b.d_dangling, rows));
-    HIP_TRY_B(hipMalloc((void**)&b.d_scale, rows * 32));
-    HIP_TRY_B(hipMalloc((void**)&b.d_inw, (size_t)n_sets * 32));
-    HIP_TRY_B(hipMalloc((void**)&b.d_pre, (size_t)n_sets * 4));
-    HIP_TRY_B(hipMalloc((void**)&b.d_out, rows * 32));
-    HIP_TRY_B(hipMalloc((void**)&b.d_status, (size_t)n_sets * 4));
+    BATCH_ALLOC(b.d_member, rows);
+    BATCH_ALLOC(b.d_dangling, rows);
+    BATCH_ALLOC(b.d_scale, rows * 32);
+    BATCH_ALLOC(b.d_inw, (size_t)n_sets * 32);
+    BATCH_ALLOC(b.d_pre, (size_t)n_sets * 4);
+    BATCH_ALLOC(b.d_out, rows * 32);
+    BATCH_ALLOC(b.d_status, (size_t)n_sets * 4);
     HIP_TRY_B(hipMemcpy(b.d_member, mem.data(), rows, hipMemcpyHostToDevice));
     HIP_TRY_B(hipMemcpy(b.d_dangling, dang.data(), rows, hipMemcpyHostToDevice));
     HIP_TRY_B(hipMemcpy(b.d_scale, scale.data(), rows * 32, hipMemcpyHostToDevice));
@@ -859,6 +888,12 @@ int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const ui
     HIP_TRY_B(hipMemcpy(b.d_pre, pre.data(), (size_t)n_sets * 4, hipMemcpyHostToDevice));
     *out = h.release();
     return ET_OK;
+}
+
+extern "C" {
+
+int et_batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, const uint32_t* values, int device, et_batch** out) {
+    return batch_create(n_sets, n, member, values, device, nullptr, out);
 }
 
 void et_batch_free(et_batch* b) { delete b; }
@@ -940,6 +975,61 @@ int et_batch_edges(const et_batch* h, uint64_t* edges) {
     if (!h || !edges) return ET_E_INVALID_ARG;
     *edges = h->b.edges;
     return ET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The variant of et_batch_converge_fr that allocates no device memory.  Everything the batch kernels need beyond
+// the caller's host arrays (the filtered, transposed opinion bytes, column sums, factors, member flags, per-set
+// status, and the staging of the scores) lives in ONE array that is part of the library's code object: every GPU
+// the library runs on holds its own copy, at its own address, from the first call on it until the process ends.
+// Host code never uses the array's name as an address (on the host it is only a handle): the device address is
+// asked for once per device, with that device current, and kept.
+// ---------------------------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[ET_NOALLOC_SCRATCH_BYTES];
+
+static std::mutex g_scratch_lock;                   // the array is shared by every call on a GPU: one at a time
+static void* g_scratch_ptr[ET_NOALLOC_MAX_DEVICES]; // per device: address of that GPU's copy, null until first use
+
+// Address of the current device's copy of the array (device `dev` must be current).
+static int scratch_address(int dev, void** out) {
+    if (dev < 0 || dev >= ET_NOALLOC_MAX_DEVICES) { set_error("device ordinal out of range"); return ET_E_OUT_OF_RANGE; }
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        HIP_TRY_B(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) { set_error("hipGetSymbolAddress returned a null address"); return ET_E_HIP; }
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return ET_OK;
+}
+
+int et_batch_converge_fr_noalloc(uint32_t n_sets, uint32_t n, const uint8_t* member, const uint32_t* values,
+                                 uint32_t num_iterations, uint64_t initial_lo, uint64_t initial_hi, et_fr* out,
+                                 int32_t* status) {
+    if (!values || !out || n_sets == 0 || n == 0) return ET_E_INVALID_ARG;
+    int ndev = 0, dev = -1;
+    HIP_TRY_B(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { set_error("no HIP device"); return ET_E_NO_DEVICE; }
+    HIP_TRY_B(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    void* base = nullptr;
+    int rc = scratch_address(dev, &base);
+    if (rc) return rc;
+    Arena arena;
+    arena.base = static_cast<uint8_t*>(base);
+    arena.cap = ET_NOALLOC_SCRATCH_BYTES;
+    et_batch* b = nullptr;
+    // carves the batch's arrays out of the scratch array and fills all of them except scores and status; a batch
+    // that needs more than the array holds is refused there (ET_E_BUFFER_TOO_SMALL)
+    rc = batch_create(n_sets, n, member, values, dev, &arena, &b);
+    if (rc) return rc;
+    std::unique_ptr<et_batch> own(b);                // host-side object only: its device arrays are not freed
+    // the array keeps the previous call's contents: scores and status start from zero
+    HIP_TRY_B(hipMemsetAsync(b->b.d_out, 0, (size_t)n_sets * n * 32, nullptr));
+    HIP_TRY_B(hipMemsetAsync(b->b.d_status, 0, (size_t)n_sets * 4, nullptr));
+    rc = et_batch_run_fr_async(b, num_iterations, initial_lo, initial_hi, nullptr);
+    if (!rc) rc = et_batch_result_fr(b, out, status, nullptr);   // copies back and waits for the stream
+    return rc;
 }
 
 int et_batch_converge_fr(uint32_t n_sets, uint32_t n, const uint8_t* member, const uint32_t* values, uint32_t num_iterations,
