@@ -188,6 +188,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libeigentrust_hip.so not found at %s; run `make -C protocol_amd/csrc` "
                               "(or __graft_entry__.build())" % LIB_PATH)
+        # A process must hold ONE HIP runtime.  PyTorch ships its own copy and loads it globally; the library then
+        # binds to that copy -- but only when PyTorch's is in the process first.  Loaded the other way round, the
+        # system runtime initialises the GPU for the library and PyTorch's copy finds no device afterwards.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)

@@ -186,25 +186,31 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         geo.nd_cap = std::max<uint32_t>(geo.nd_cap, (geo.f64_dblocks + 15) / 16 * 16);
         // exact blocked sweep: whole rounds of 256 workgroups of about 2048 rows (64 bytes of LDS per row); only
         // where it was measured to pay
-        geo.fr_blocks = geo.fr_rb = geo.fr_dblocks = 0;
+        geo.fr_blocks = geo.fr_rb = geo.fr_dblocks = geo.fr_compact = 0;
         bool bytes_only = in.val_u32 != nullptr && !getenv("ET_FR_ROW_PER_LANE");
-        if (bytes_only && G == 1 && geo.rows_cap >= (1u << 19) && geo.rows_cap <= (1u << 21)) {
+        // several shares: only on request (ET_FR_SWEEP_SHARES=1) -- with the rows of a share spread over eight L2s
+        // and a vector eight times the share's rows, a swept line serves about one edge per L2
+        const bool window = (G == 1 || getenv("ET_FR_SWEEP_SHARES")) && geo.rows_cap >= (1u << 19) && geo.rows_cap <= (1u << 21);
+        if (bytes_only && window) {
             uint32_t vmax = 0;
             for (uint64_t k = 0; k < in.n_edges; ++k) vmax |= in.val_u32[k];
             bytes_only = vmax <= 255;
         }
-        if (bytes_only && G == 1 && geo.rows_cap >= (1u << 19) && geo.rows_cap <= (1u << 21)) {
-            const uint32_t Bf = (geo.rows_cap / 2048 + 255) / 256 * 256;
+        if (bytes_only && window) {
+            // whole rounds of 256 workgroups (one per CU), as few as the rows' LDS footprint allows: every round
+            // pulls the whole vector through every L2 again
+            const bool compact = !getenv("ET_FR_WIDE_ROWS");          // measurement knob: the 64-byte rows
+            const uint32_t rb_max = compact ? FR_RB_MAX_COMPACT : FR_RB_MAX_WIDE;
+            uint32_t Bf = 256;
+            while ((n_groups + Bf - 1) / Bf * BLOCK_GROUP > rb_max) Bf += 256;
             const uint32_t even_f = (n_groups + Bf - 1) / Bf;
             // no spare accumulator slots: every workgroup holds exactly its share of the row groups (the deal still
-            // levels the edges to about 2 %), so that its 1024 threads finish the rows in two full passes
-            const uint32_t rb = even_f * BLOCK_GROUP;
-            if (rb <= 2432) {
-                geo.fr_blocks = Bf;
-                geo.fr_rb = rb;
-                geo.fr_dblocks = dangling_blocks(Bf, rb / BLOCK_GROUP, geo.n_dangling_pad / BLOCK_GROUP / G);
-                geo.nd_cap = std::max<uint32_t>(geo.nd_cap, (geo.fr_dblocks + 15) / 16 * 16);
-            }
+            // levels the edges to about 2 %), so that its 1024 threads finish the rows in full passes
+            geo.fr_blocks = Bf;
+            geo.fr_rb = even_f * BLOCK_GROUP;
+            geo.fr_compact = compact ? 1u : 0u;
+            geo.fr_dblocks = dangling_blocks(Bf, geo.fr_rb / BLOCK_GROUP, geo.n_dangling_pad / BLOCK_GROUP / G);
+            geo.nd_cap = std::max<uint32_t>(geo.nd_cap, (geo.fr_dblocks + 15) / 16 * 16);
         }
     }
     g.geo = geo;

@@ -649,6 +649,7 @@ struct StepArgsFrB {
     uint32_t* chg_part;       // [fr_blocks]
     Geometry geo;
     uint32_t final_step;
+    uint32_t debug;           // measurement only: bit 0 skips the sweep, bit 1 the rows (results are then wrong)
     U256 inv_nm1_w;
     U256 inv_nm1_w576;        // inv(n_valid - 1) * 2^576
 };
@@ -663,8 +664,16 @@ __global__ void k_scale_288(const uint4* __restrict__ scale576, uint4* __restric
     u256_store(scale288 + 2 * i, acc_redc288(t));
 }
 
+// COMPACT: a row's sum as nine 32-bit limbs, stored as four 64-bit words [4][RB] followed by the top limbs [RB]
+// (36 bytes per row, so one workgroup per CU covers 1M rows in ONE round and the vector crosses every L2 once).
+// An edge adds its 264-bit product word by word with LDS atomics that return the old word: the add that wraps a word
+// is the one that sees it, and sends the carry into the next word (a carry that wraps a word of all ones travels
+// on).  Each wrap is compensated exactly once, every addend is non-negative and the final sum is below 2^288, so once
+// all adds have landed the limbs hold the exact integer whatever the order.
+// !COMPACT: eight 64-bit column sums per row [8][RB] (limb times opinion byte, no carries until the row is folded).
+template <bool COMPACT>
 __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
-    extern __shared__ unsigned long long colsum_l[];   // [8][RB]
+    extern __shared__ unsigned long long colsum_l[];
     __shared__ uint32_t sh_d[9];
     __shared__ uint32_t sh_pd[17];
     __shared__ uint32_t sh_pdr[8];
@@ -675,7 +684,12 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     const uint32_t b = blockIdx.x, RB = a.geo.fr_rb;
     const uint32_t stride = a.geo.seg_stride();
     const size_t my_base = (size_t)a.geo.seg * stride;
-    for (uint32_t i = threadIdx.x; i < 8 * RB; i += 1024) colsum_l[i] = 0;
+    uint32_t* const top_l = reinterpret_cast<uint32_t*>(colsum_l + 4 * (size_t)RB);   // COMPACT: limb 8 of every row
+    if (COMPACT) {
+        for (uint32_t i = threadIdx.x; i < 4 * RB + RB / 2; i += 1024) colsum_l[i] = 0;   // RB is a multiple of 16
+    } else {
+        for (uint32_t i = threadIdx.x; i < 8 * RB; i += 1024) colsum_l[i] = 0;
+    }
     // partial-sum slots no workgroup writes: zero, whatever the caller's buffer held (see fr_zero_unused_tail)
     fr_zero_unused_tail(a.y, a.geo, a.geo.fr_dblocks, 1024);
     __syncthreads();
@@ -698,10 +712,45 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     // three edges per thread in flight and a barrier every second batch: 145 us on the 1M-peer benchmark graph against
     // 153 us for four (150 us for two, 156 us without the barriers' help or with a barrier every batch)
     constexpr int U = 3;
-    const uint32_t n_batches = (uint32_t)((e1 - e0) / (U * 1024));
+    uint32_t n_batches = (uint32_t)((e1 - e0) / (U * 1024));
     uint64_t e = e0 + threadIdx.x;
+    if (a.debug & 1u) { n_batches = 0; e = e1; }
+    // a carry into word k of a row (k = 1..3), or into the top limb (k = 4)
+    auto carry_into = [&](uint32_t slot, uint32_t k) {
+        for (; k < 4; ++k)
+            if (atomicAdd(colsum_l + (size_t)k * RB + slot, 1ull) != ~0ull) return;
+        atomicAdd(top_l + slot, 1u);
+    };
     auto add_edge = [&](uint32_t slot, uint32_t v, const uint4& lo, const uint4& hi) {
         unsigned long long* p = colsum_l + slot;
+        if (COMPACT) {
+            // the 264-bit product opinion * xs as four 64-bit words and a top byte
+            uint64_t t = (uint64_t)lo.x * v;
+            uint64_t w0 = (uint32_t)t;
+            t = (uint64_t)lo.y * v + (t >> 32); w0 |= t << 32;
+            t = (uint64_t)lo.z * v + (t >> 32);
+            uint64_t w1 = (uint32_t)t;
+            t = (uint64_t)lo.w * v + (t >> 32); w1 |= t << 32;
+            t = (uint64_t)hi.x * v + (t >> 32);
+            uint64_t w2 = (uint32_t)t;
+            t = (uint64_t)hi.y * v + (t >> 32); w2 |= t << 32;
+            t = (uint64_t)hi.z * v + (t >> 32);
+            uint64_t w3 = (uint32_t)t;
+            t = (uint64_t)hi.w * v + (t >> 32); w3 |= t << 32;
+            uint32_t w4 = (uint32_t)(t >> 32);
+            const uint64_t o0 = atomicAdd(p + 0 * (size_t)RB, (unsigned long long)w0);
+            const uint64_t o1 = atomicAdd(p + 1 * (size_t)RB, (unsigned long long)w1);
+            const uint64_t o2 = atomicAdd(p + 2 * (size_t)RB, (unsigned long long)w2);
+            const uint64_t o3 = atomicAdd(p + 3 * (size_t)RB, (unsigned long long)w3);
+            // old + addend wrapped  <=>  old > ~addend
+            const bool c1 = o0 > ~w0, c2 = o1 > ~w1, c3 = o2 > ~w2;
+            w4 += o3 > ~w3 ? 1u : 0u;
+            if (w4) atomicAdd(top_l + slot, w4);
+            if (c1) carry_into(slot, 1);
+            if (c2) carry_into(slot, 2);
+            if (c3) carry_into(slot, 3);
+            return;
+        }
         atomicAdd(p + 0 * RB, (unsigned long long)lo.x * v);
         atomicAdd(p + 1 * RB, (unsigned long long)lo.y * v);
         atomicAdd(p + 2 * RB, (unsigned long long)lo.z * v);
@@ -754,6 +803,17 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     uint32_t changed = 0;
     // eight 64-bit column sums, 32 bits apart, as ten limbs
     auto fold_row = [&](uint32_t lr, uint32_t* t) {
+        if (COMPACT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned long long w = colsum_l[lr + (size_t)j * RB];
+                t[2 * j] = (uint32_t)w;
+                t[2 * j + 1] = (uint32_t)(w >> 32);
+            }
+            t[8] = top_l[lr];
+            t[9] = 0;
+            return;
+        }
         uint64_t c = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -767,7 +827,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     };
     // rows with opinions first (the common case, no dangling arithmetic in the loop), then the dangling rows, which
     // only the leading workgroups hold
-    for (uint32_t lr = threadIdx.x; lr < RB; lr += 1024) {
+    for (uint32_t lr = threadIdx.x; lr < ((a.debug & 2u) ? 0u : RB); lr += 1024) {
         const uint32_t grp = a.grp[(size_t)b * (RB / BLOCK_GROUP) + lr / BLOCK_GROUP];
         if (grp == 0xFFFFFFFFu) continue;
         const uint32_t row = grp * BLOCK_GROUP + lr % BLOCK_GROUP;
@@ -1081,7 +1141,8 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
             if ((rc = dev_upload(&g->d_fb_ptr, h.fb_ptr, tot)) || (rc = dev_upload(&g->d_fb_grp, h.fb_grp, tot)) ||
                 (rc = dev_upload(&g->d_fb_col, h.fb_col, tot)) || (rc = dev_upload(&g->d_fb_row, h.fb_row, tot)) ||
                 (rc = dev_upload(&g->d_fb_val, h.fb_val, tot))) return rc;
-            HIP_TRY(hipFuncSetAttribute((const void*)k_step_fr_blocked, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_step_fr_blocked<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_step_fr_blocked<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
             // the sweep multiplies unreduced row sums by inv(sum) * 2^288 (the resident factors carry 2^576)
             if ((rc = dev_alloc(&g->d_fb_scale, vec_len * 2, tot))) return rc;
             hipLaunchKernelGGL(k_scale_288, dim3((unsigned)((vec_len + 255) / 256)), dim3(256), 0, 0, g->d_scale_fr, g->d_fb_scale, vec_len);
@@ -1159,8 +1220,10 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
         fb.ptr = d_fb_ptr; fb.grp = d_fb_grp; fb.col = d_fb_col; fb.row = d_fb_row; fb.val = d_fb_val; fb.x = x; fb.y = y;
         fb.own = own_fr; fb.scale288 = d_fb_scale; fb.sum_part = d_frsum_part + 2 * ringb; fb.chg_part = d_chg_part + ringb;
         fb.geo = geo; fb.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u; fb.inv_nm1_w = to_u256(inv_nm1_w);
+        { const char* dbg = getenv("ET_FR_DEBUG"); fb.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }
         fb.inv_nm1_w576 = to_u256((Fr::from_raw(inv_nm1_w) * Fr::one().pow2k(288)).to_raw());
-        hipLaunchKernelGGL(k_step_fr_blocked, dim3(geo.fr_blocks), dim3(1024), (size_t)geo.fr_rb * 64, st, fb);
+        if (geo.fr_compact) hipLaunchKernelGGL(k_step_fr_blocked<true>, dim3(geo.fr_blocks), dim3(1024), (size_t)geo.fr_rb * 36, st, fb);
+        else hipLaunchKernelGGL(k_step_fr_blocked<false>, dim3(geo.fr_blocks), dim3(1024), (size_t)geo.fr_rb * 64, st, fb);
         HIP_TRY(hipGetLastError());
         return ET_OK;
     }

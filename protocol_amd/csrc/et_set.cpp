@@ -28,6 +28,17 @@ struct et_set {
     std::vector<uint8_t> has_row;
     std::vector<std::vector<std::pair<uint32_t, FrRaw>>> rows;
     bool all_u32 = true;        // every stored opinion fits 32 bits
+    // The reference's converge takes &self and is called again and again between membership changes
+    // (native.rs:873-878): the device-resident form of the set is kept until the set changes, so that a repeated
+    // converge is a launch and a copy, with no allocation and no upload.
+    uint64_t version = 1;       // bumped by every call that changes members or opinions
+    et_batch* dev_batch = nullptr;
+    DeviceGraph* dev_graph[2] = {nullptr, nullptr};   // exact variant, f64 variant
+    uint64_t batch_version = 0, graph_version[2] = {0, 0};
+    ~et_set() {
+        if (dev_batch) et_batch_free(dev_batch);
+        for (DeviceGraph* g : dev_graph) delete g;
+    }
 
     int find(const FrRaw& a) const {
         for (uint32_t i = 0; i < n; ++i) if (addr[i] == a) return (int)i;
@@ -73,6 +84,7 @@ int et_set_add_member(et_set* s, const et_fr* addr) {
     s->score[idx] = Fr::from_u128(s->init_lo, s->init_hi).to_raw();    // native.rs:184-185
     s->has_row[idx] = 0;
     s->rows[idx].clear();
+    ++s->version;
     return ET_OK;
 }
 
@@ -87,6 +99,7 @@ int et_set_remove_member(et_set* s, const et_fr* addr) {
     s->score[idx] = FrRaw{{0, 0, 0, 0}};
     s->has_row[idx] = 0;                                                // native.rs:197
     s->rows[idx].clear();
+    ++s->version;
     return ET_OK;
 }
 
@@ -110,6 +123,7 @@ static int store_row(et_set* s, int from_slot, uint32_t count, const uint32_t* a
         dst.push_back(kv);
     }
     s->has_row[from_slot] = 1;                                          // native.rs:228
+    ++s->version;
     return ET_OK;
 }
 
@@ -165,6 +179,20 @@ static void flatten(const et_set* s, std::vector<uint8_t>& member, std::vector<u
     }
 }
 
+// The device-resident graph of the set for one variant (0 = exact, 1 = f64), rebuilt only after the set changed.
+static int build_for_set(const et_set* s, int variants, DeviceGraph** out);
+static int graph_for_set(et_set* s, int which, DeviceGraph** out) {
+    if (!s->dev_graph[which] || s->graph_version[which] != s->version) {
+        delete s->dev_graph[which];
+        s->dev_graph[which] = nullptr;
+        int rc = build_for_set(s, which == 0 ? ET_VARIANT_FR : ET_VARIANT_F64, &s->dev_graph[which]);
+        if (rc) return rc;
+        s->graph_version[which] = s->version;
+    }
+    *out = s->dev_graph[which];
+    return ET_OK;
+}
+
 static int build_for_set(const et_set* s, int variants, DeviceGraph** out) {
     std::vector<uint8_t> member;
     std::vector<uint32_t> from, to, v32;
@@ -197,35 +225,41 @@ int et_set_converge(et_set* s, et_fr* out) {
     }
     if (s->n <= 1024 && s->all_u32) {
         // small set: one workgroup runs the whole converge in a single launch (batch of one)
-        std::vector<uint8_t> member(s->n);
-        std::vector<uint32_t> dense((size_t)s->n * s->n, 0);
-        for (uint32_t i = 0; i < s->n; ++i) {
-            member[i] = !s->addr[i].is_zero();
-            if (member[i] && s->has_row[i])
-                for (auto& kv : s->rows[i]) dense[(size_t)i * s->n + kv.first] = (uint32_t)kv.second.l[0];
+        if (!s->dev_batch || s->batch_version != s->version) {
+            if (s->dev_batch) et_batch_free(s->dev_batch);
+            s->dev_batch = nullptr;
+            std::vector<uint8_t> member(s->n);
+            std::vector<uint32_t> dense((size_t)s->n * s->n, 0);
+            for (uint32_t i = 0; i < s->n; ++i) {
+                member[i] = !s->addr[i].is_zero();
+                if (member[i] && s->has_row[i])
+                    for (auto& kv : s->rows[i]) dense[(size_t)i * s->n + kv.first] = (uint32_t)kv.second.l[0];
+            }
+            int rc = et_batch_create(1, s->n, member.data(), dense.data(), -1, &s->dev_batch);
+            if (rc) return rc;
+            s->batch_version = s->version;
         }
         int32_t status = ET_OK;
-        int rc = et_batch_converge_fr(1, s->n, member.data(), dense.data(), s->num_iter, s->init_lo, s->init_hi, out, &status);
+        int rc = et_batch_run_fr_async(s->dev_batch, s->num_iter, s->init_lo, s->init_hi, nullptr);
+        if (!rc) rc = et_batch_result_fr(s->dev_batch, out, &status, nullptr);
         if (rc) return rc;
         if (status == ET_E_INSUFFICIENT_PEERS) set_error("Insufficient peers for calculation!");
         if (status == ET_E_SUM_MISMATCH) set_error("reputation leak: field sum of scores changed");
         return status;
     }
-    DeviceGraph* gp = nullptr;
-    int rc = build_for_set(s, ET_VARIANT_FR, &gp);
+    DeviceGraph* g = nullptr;
+    int rc = graph_for_set(s, 0, &g);
     if (rc) return rc;
-    std::unique_ptr<DeviceGraph> g(gp);
-    return et_graph_converge_fr(reinterpret_cast<et_graph*>(g.get()), s->num_iter, s->init_lo, s->init_hi, out);
+    return et_graph_converge_fr(reinterpret_cast<et_graph*>(g), s->num_iter, s->init_lo, s->init_hi, out);
 }
 
 int et_set_converge_f64(et_set* s, double alpha, const double* pretrust, double* out, double* residual_l1) {
     if (!s || !out) return ET_E_INVALID_ARG;
-    DeviceGraph* gp = nullptr;
-    int rc = build_for_set(s, ET_VARIANT_F64, &gp);
+    DeviceGraph* g = nullptr;
+    int rc = graph_for_set(s, 1, &g);
     if (rc) return rc;
-    std::unique_ptr<DeviceGraph> g(gp);
     double initial = (double)s->init_lo + 18446744073709551616.0 * (double)s->init_hi;
-    return et_graph_converge_f64(reinterpret_cast<et_graph*>(g.get()), s->num_iter, initial, alpha, pretrust, out, residual_l1);
+    return et_graph_converge_f64(reinterpret_cast<et_graph*>(g), s->num_iter, initial, alpha, pretrust, out, residual_l1);
 }
 
 // converge_rational, native.rs:340-392

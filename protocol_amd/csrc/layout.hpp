@@ -65,6 +65,7 @@ inline uint32_t dangling_blocks(uint32_t blocks, uint32_t groups_per_block, uint
     uint32_t d = need > 256 ? need : 256;
     return d < blocks ? d : blocks;
 }
+static const uint32_t FR_RB_MAX_COMPACT = 4400, FR_RB_MAX_WIDE = 2432;
 // A source index in an edge record: segment in the top 3 bits, local row below.
 static const uint32_t COL_SEG_SHIFT = 29;
 static const uint32_t COL_LOCAL_MASK = (1u << COL_SEG_SHIFT) - 1;
@@ -85,9 +86,11 @@ struct Geometry {
     // groups of dangling rows go to the first f64_dblocks workgroups only; workgroup b of those writes
     // partial-sum slot b of its segment, so nd_cap >= f64_dblocks
     uint32_t f64_dblocks;
-    // exact blocked sweep (byte opinions, one share, 512K to 2M rows; 0 workgroups = not used): the same deal with
-    // eight 64-bit column sums per row in LDS, so at most 2432 rows per workgroup
-    uint32_t fr_blocks, fr_rb, fr_dblocks;
+    // exact blocked sweep (byte opinions, 512K to 2M rows per share; 0 workgroups = not used): the same deal with a
+    // row's unreduced sum in LDS.  fr_compact != 0: nine 32-bit limbs per row (36 bytes, carries propagated as the
+    // edges arrive), up to FR_RB_MAX_COMPACT rows per workgroup; else eight 64-bit column sums (64 bytes, no carries
+    // until the row is folded), up to FR_RB_MAX_WIDE rows.
+    uint32_t fr_blocks, fr_rb, fr_dblocks, fr_compact;
     ET_HD uint32_t seg_stride() const { return rows_cap + nd_cap; }
     ET_HD uint32_t pos_of_col(uint32_t c) const { return (c >> COL_SEG_SHIFT) * seg_stride() + (c & COL_LOCAL_MASK); }
 };
