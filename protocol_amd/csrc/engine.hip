@@ -200,6 +200,27 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
             dv[u] = xr[(size_t)sg * stride + a.geo.rows_cap + k];
         }
     }
+    // The rows' epilogue needs, per row, its group entry and then the old score and the factor: two dependent trips to
+    // memory with nothing else left to do.  The first four rows of every thread (all of them when the workgroup holds
+    // at most 4096) are asked for here, before the sweep, and wait in registers.
+    uint32_t pgrp[4];
+    double pold[4], psc[4], ppt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t lr = threadIdx.x + u * 1024;
+        pgrp[u] = lr < RB ? a.grp[(size_t)b * (RB / BLOCK_GROUP) + lr / BLOCK_GROUP] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t lr = threadIdx.x + u * 1024;
+        const uint32_t row = pgrp[u] * BLOCK_GROUP + lr % BLOCK_GROUP;
+        pold[u] = psc[u] = ppt[u] = 0.0;
+        if (pgrp[u] != 0xFFFFFFFFu) {                      // rows beyond the members read a valid address and are dropped later
+            pold[u] = RAW ? a.own[row] : xr[my_base + row];
+            if (RAW && !a.final_step) psc[u] = a.scale[my_base + row];
+            if (HAS_ALPHA) ppt[u] = a.pretrust[my_base + row];
+        }
+    }
     __syncthreads();
 
     const uint64_t e0 = a.bk_ptr[b], e1 = a.bk_ptr[b + 1];
@@ -261,10 +282,11 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
         uint32_t grp[4], row[4];
         bool live[4], dang[4];
         double old[4], sc[4], pt[4];
+        const bool first = lr0 == threadIdx.x;             // this pass was asked for before the sweep
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t lr = lr0 + u * 1024;
-            grp[u] = lr < RB ? a.grp[(size_t)b * (RB / BLOCK_GROUP) + lr / BLOCK_GROUP] : 0xFFFFFFFFu;
+            grp[u] = first ? pgrp[u] : (lr < RB ? a.grp[(size_t)b * (RB / BLOCK_GROUP) + lr / BLOCK_GROUP] : 0xFFFFFFFFu);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -275,7 +297,9 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
             dang[u] = q >= a.geo.n_active_pad && q < (uint64_t)a.geo.n_active_pad + a.geo.n_dangling;
             live[u] = grp[u] != 0xFFFFFFFFu && (active || dang[u]);
             old[u] = sc[u] = pt[u] = 0.0;
-            if (live[u]) {
+            if (first) {
+                if (live[u]) { old[u] = pold[u]; sc[u] = psc[u]; pt[u] = ppt[u]; }
+            } else if (live[u]) {
                 old[u] = RAW ? a.own[row[u]] : xr[my_base + row[u]];
                 if (RAW && !a.final_step) sc[u] = a.scale[my_base + row[u]];
                 if (HAS_ALPHA) pt[u] = a.pretrust[my_base + row[u]];
