@@ -38,6 +38,7 @@ pub const ET_E_RATIONAL_TOO_LARGE: c_int = -18;
 pub const ET_E_PARSE: c_int = -19;
 pub const ET_E_BAD_SIGNATURE: c_int = -20;
 pub const ET_E_BAD_ABOUT: c_int = -21;
+pub const ET_E_RCCL: c_int = -22;
 
 pub const ET_VARIANT_FR: u32 = 1;
 pub const ET_VARIANT_F64: u32 = 2;
@@ -60,6 +61,13 @@ pub struct et_plan {
 pub struct et_batch {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct et_sharded {
+    _private: [u8; 0],
+}
+pub const ET_EXCHANGE_AUTO: u32 = 0;
+pub const ET_EXCHANGE_RCCL: u32 = 1;
+pub const ET_EXCHANGE_COPY: u32 = 2;
 
 #[repr(C)]
 #[derive(Clone, Copy, Default)]
@@ -241,6 +249,18 @@ extern "C" {
     /// The same without any device allocation (the batch lives in the library's resident scratch array).
     pub fn et_batch_converge_fr_noalloc(n_sets: u32, n: u32, member: *const u8, values: *const u32, num_iterations: u32,
                                         initial_lo: u64, initial_hi: u64, out: *mut et_fr, status: *mut i32) -> c_int;
+
+    /// Row-sharded converge over the GPUs of one node from one host thread (RCCL all-gather or device copies).
+    pub fn et_sharded_create(n: u32, member: *const u8, n_edges: u64, from: *const u32, to: *const u32,
+                             value_u32: *const u32, value_fr: *const et_fr, n_devices: u32, devices: *const i32,
+                             variants: u32, exchange: u32, out: *mut *mut et_sharded) -> c_int;
+    pub fn et_sharded_free(s: *mut et_sharded);
+    pub fn et_sharded_exchange_kind(s: *const et_sharded) -> c_int;
+    pub fn et_sharded_info_get(s: *const et_sharded, share: u32, info: *mut et_graph_info) -> c_int;
+    pub fn et_sharded_converge_fr(s: *mut et_sharded, num_iterations: u32, initial_lo: u64, initial_hi: u64,
+                                  out: *mut et_fr) -> c_int;
+    pub fn et_sharded_converge_f64(s: *mut et_sharded, num_iterations: u32, initial: f64, alpha: f64,
+                                   pretrust: *const f64, out: *mut f64, residual_l1: *mut f64) -> c_int;
 
     pub fn et_synth_graph(kind: u32, n: u32, target_edges: u64, seed: u64, value_max: u32, n_edges: *mut u64,
                           from: *mut u32, to: *mut u32, value: *mut u32) -> c_int;

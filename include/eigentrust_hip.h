@@ -53,7 +53,8 @@ enum {
     ET_E_RATIONAL_TOO_LARGE = -18,/* eigentrust/src/lib.rs:222-229  magnitude over 32 bytes   */
     ET_E_PARSE = -19,             /* storage.rs:286-331, circuit.rs:128-132  malformed input  */
     ET_E_BAD_SIGNATURE = -20,     /* ecdsa/native.rs:202-203, :316, :322-327  unwrap / assert */
-    ET_E_BAD_ABOUT = -21          /* opinion/native.rs:75  attestation about another peer     */
+    ET_E_BAD_ABOUT = -21,         /* opinion/native.rs:75  attestation about another peer     */
+    ET_E_RCCL = -22               /* an RCCL call failed or librccl could not be loaded       */
 };
 
 const char *et_strerror(int code);
@@ -196,8 +197,9 @@ int et_graph_converge_f64(et_graph *g, uint32_t num_iterations, double initial, 
 
 /* ---- device-resident stepping (benches, the sharded multi-GPU driver) ------------------------
  * Trust vectors are device buffers of vec_len entries in position order (et_fr = 32 bytes, or
- * double), allocated by the caller.  `stream` is a hipStream_t (NULL = default stream).  These
- * calls only enqueue work and allocate nothing. */
+ * double), allocated by the caller; they need no zero fill (init and every step write their whole
+ * segment, partial-sum tail included).  `stream` is a hipStream_t (NULL = default stream).  These
+ * calls make the graph's device current, only enqueue work and allocate nothing. */
 
 /* Writes this share's segment of the initial vector (INITIAL_SCORE for members, native.rs:184,317)
  * plus its partial sums into x; other segments are left untouched (all-gather them).  Without
@@ -254,6 +256,33 @@ int et_graph_event_times(et_graph *g, float *total_ms, uint32_t *pairs);
 /* Copies the result of the last et_graph_run_* to the host (n entries, slot order). */
 int et_graph_result_fr(et_graph *g, et_fr *out, void *stream);
 int et_graph_result_f64(et_graph *g, double *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row-sharded converge over the GPUs of one node, driven by ONE host thread (a Rust caller has no
+ * torch.distributed).  The reference has no counterpart: its converge runs one dense matrix on one core
+ * (native.rs:286-337); results here are the same bits as et_graph_converge_fr on one GPU.
+ * Rows are dealt to n_devices shares (<= 8); per iteration every GPU runs the step on its rows and the
+ * segments are exchanged once: RCCL all-gather over xGMI, or device-to-device pulls ordered by events.
+ *   devices  : n_devices HIP ordinals.  Listing a device more than once rehearses the N-share layout on
+ *              fewer GPUs (exchange by copies: RCCL refuses two ranks of a communicator on one device).
+ *   exchange : ET_EXCHANGE_AUTO = RCCL when the devices are distinct and librccl loads, else copies.
+ * Errors: those of et_graph_build, ET_E_RCCL, ET_E_SUM_MISMATCH (native.rs:334).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct et_sharded et_sharded;
+enum { ET_EXCHANGE_AUTO = 0, ET_EXCHANGE_RCCL = 1, ET_EXCHANGE_COPY = 2 };
+int et_sharded_create(uint32_t n, const uint8_t *member, uint64_t n_edges, const uint32_t *from,
+                      const uint32_t *to, const uint32_t *value_u32, const et_fr *value_fr,
+                      uint32_t n_devices, const int32_t *devices, uint32_t variants, uint32_t exchange,
+                      et_sharded **out);
+void et_sharded_free(et_sharded *s);
+/* ET_EXCHANGE_RCCL or ET_EXCHANGE_COPY: what et_sharded_create settled on. */
+int et_sharded_exchange_kind(const et_sharded *s);
+int et_sharded_info_get(const et_sharded *s, uint32_t share, et_graph_info *info);
+/* Whole converge: scores for all n slots in slot order (host buffers); synchronous. */
+int et_sharded_converge_fr(et_sharded *s, uint32_t num_iterations, uint64_t initial_lo,
+                           uint64_t initial_hi, et_fr *out);
+int et_sharded_converge_f64(et_sharded *s, uint32_t num_iterations, double initial, double alpha,
+                            const double *pretrust, double *out, double *residual_l1);
 
 /* ------------------------------------------------------------------------------------------
  * Batches of small independent sets (ZK witness generation): n_sets sets of n <= 1024 slots.

@@ -31,9 +31,11 @@ ET_E_RATIONAL_TOO_LARGE = -18
 ET_E_PARSE = -19
 ET_E_BAD_SIGNATURE = -20
 ET_E_BAD_ABOUT = -21
+ET_E_RCCL = -22
 
 ET_VARIANT_FR = 1
 ET_VARIANT_F64 = 2
+ET_EXCHANGE_AUTO, ET_EXCHANGE_RCCL, ET_EXCHANGE_COPY = 0, 1, 2
 
 
 class EtFr(C.Structure):
@@ -136,6 +138,12 @@ PROTOTYPES = {
     "et_graph_event_times": (i32, [vp, P(C.c_float), P(u32)]),
     "et_graph_result_fr": (i32, [vp, vp, vp]),
     "et_graph_result_f64": (i32, [vp, vp, vp]),
+    "et_sharded_create": (i32, [u32, vp, u64, vp, vp, vp, vp, u32, vp, u32, u32, P(vp)]),
+    "et_sharded_free": (None, [vp]),
+    "et_sharded_exchange_kind": (i32, [vp]),
+    "et_sharded_info_get": (i32, [vp, u32, P(EtGraphInfo)]),
+    "et_sharded_converge_fr": (i32, [vp, u32, u64, u64, vp]),
+    "et_sharded_converge_f64": (i32, [vp, u32, dbl, dbl, vp, vp, P(dbl)]),
     "et_batch_create": (i32, [u32, u32, vp, vp, i32, P(vp)]),
     "et_batch_free": (None, [vp]),
     "et_batch_run_fr_async": (i32, [vp, u32, u64, u64, vp]),

@@ -24,7 +24,8 @@ struct Pos {  // global sorted row -> (segment, local row, position)
 
 }  // namespace
 
-int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::string& err) {
+int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& pc, std::string& err) {
+    HostGraph& g = pc.g;
     const uint32_t n = in.n;
     if (n == 0 || (in.n_edges && (!in.from || !in.to)) || ((in.val_u32 != nullptr) == (in.val_fr != nullptr) && in.n_edges)) {
         err = "bad build input";
@@ -48,7 +49,8 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
 
     // ---- 1. filter (native.rs:248-260) and group by attester --------------------------------
     const uint64_t ne = in.n_edges;
-    std::vector<uint64_t> out_ptr((size_t)n + 1, 0);
+    std::vector<uint64_t>& out_ptr = pc.out_ptr;
+    out_ptr.assign((size_t)n + 1, 0);
     for (uint64_t e = 0; e < ne; ++e) {
         uint32_t f = in.from[e], t = in.to[e];
         if (f >= n || t >= n) {
@@ -61,7 +63,8 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     for (uint32_t i = 0; i < n; ++i) out_ptr[i + 1] += out_ptr[i];
     const uint64_t m0 = out_ptr[n];
     // kept[k] = original edge index, grouped by attester, original order inside a group
-    std::vector<uint64_t> kept(m0);
+    std::vector<uint64_t>& kept = pc.kept;
+    kept.assign(m0, 0);
     {
         std::vector<uint64_t> cur(out_ptr.begin(), out_ptr.end() - 1);
         for (uint64_t e = 0; e < ne; ++e) {
@@ -71,7 +74,8 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         }
     }
     // ---- 2. inside each attester: order by rated peer, last write wins (lib.rs:415) ---------
-    std::vector<uint8_t> drop(m0, 0);
+    std::vector<uint8_t>& drop = pc.drop;
+    drop.assign(m0, 0);
     for (uint32_t f = 0; f < n; ++f) {
         uint64_t b = out_ptr[f], e = out_ptr[f + 1];
         if (e - b < 2) continue;
@@ -105,7 +109,8 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
             }
         }
     }
-    std::vector<uint8_t> dangling(n, 0);
+    std::vector<uint8_t>& dangling = pc.dangling;
+    dangling.assign(n, 0);
     uint32_t n_dangling = 0;
     for (uint32_t i = 0; i < n; ++i) {
         if (!is_member(i)) continue;
@@ -130,7 +135,8 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     // group by in-degree (descending) so that the 64 rows of a slice have similar lengths.  Dangling
     // peers follow.
     const uint32_t n_active = n_valid - n_dangling;
-    std::vector<uint32_t> order;
+    std::vector<uint32_t>& order = pc.order;
+    order.clear();
     order.reserve(n_valid);
     for (uint32_t i = 0; i < n; ++i) if (is_member(i) && !dangling[i]) order.push_back(i);
     for (uint32_t i = 0; i < n; ++i) if (is_member(i) && dangling[i]) order.push_back(i);
@@ -188,9 +194,11 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         // where it was measured to pay
         geo.fr_blocks = geo.fr_rb = geo.fr_dblocks = geo.fr_compact = 0;
         bool bytes_only = in.val_u32 != nullptr && !getenv("ET_FR_ROW_PER_LANE");
-        // several shares: only on request (ET_FR_SWEEP_SHARES=1) -- with the rows of a share spread over eight L2s
-        // and a vector eight times the share's rows, a swept line serves about one edge per L2
-        const bool window = (G == 1 || getenv("ET_FR_SWEEP_SHARES")) && geo.rows_cap >= (1u << 19) && geo.rows_cap <= (1u << 21);
+        // from 16K rows per share upwards the sweep wins at every size and share count measured (16K peers: 19 against
+        // 30 us per iteration; one of eight shares of 16M peers: 421 against 588 us); the knobs move the bounds for tests
+        const uint32_t win_hi = getenv("ET_FR_SWEEP_MAX_ROWS") ? (uint32_t)atoll(getenv("ET_FR_SWEEP_MAX_ROWS")) : 0xFFFFFFFFu;
+        const uint32_t win_lo = getenv("ET_FR_SWEEP_MIN_ROWS") ? (uint32_t)atoll(getenv("ET_FR_SWEEP_MIN_ROWS")) : (1u << 14);
+        const bool window = geo.rows_cap >= win_lo && geo.rows_cap <= win_hi;
         if (bytes_only && window) {
             uint32_t vmax = 0;
             for (uint64_t k = 0; k < in.n_edges; ++k) vmax |= in.val_u32[k];
@@ -250,9 +258,29 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         g.inv_nm1_w = (Fr::from_u64(n_valid - 1).invert_or_zero() * Fr::one().pow2k(288)).to_raw();
     }
 
+    pc.in = in;
+    return ET_OK;
+}
+
+int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index, HostGraph& g, std::string& err) {
+    if (seg_index >= pc.g.geo.n_seg) { err = "bad segment"; return ET_E_INVALID_ARG; }
+    // everything that does not depend on the segment: filter results, order, positions, factors
+    g = pc.g;
+    g.geo.seg = seg_index;
+    const BuildInput& in = pc.in;
+    const uint32_t n = in.n, n_valid = g.n_valid;
+    const std::vector<uint64_t>& out_ptr = pc.out_ptr;
+    const std::vector<uint64_t>& kept = pc.kept;
+    const std::vector<uint8_t>& drop = pc.drop;
+    const std::vector<uint8_t>& dangling = pc.dangling;
+    const std::vector<uint32_t>& order = pc.order;
+    const Geometry geo = g.geo;
+    const uint32_t G = geo.n_seg, n_active = geo.n_active, n_dangling = geo.n_dangling;
+    const uint32_t target_work = opt.target_work ? opt.target_work : 16384;
+    (void)n_valid;
     // ---- 7. in-edges of this segment's rows, sources ascending by position -------------------
     // local row of an external peer, or ~0 when it lives in another segment
-    const uint32_t my_base = opt.seg * geo.seg_stride();
+    const uint32_t my_base = seg_index * geo.seg_stride();
     auto local_row = [&](uint32_t ext) -> uint32_t {
         uint32_t p = g.pos_of_ext[ext];
         if (p < my_base || p >= my_base + geo.rows_cap) return 0xFFFFFFFFu;
@@ -279,8 +307,9 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     });
     for (uint32_t i = 0; i < geo.rows_cap; ++i) in_ptr[i + 1] += in_ptr[i];
     g.nnz_local = in_ptr[geo.rows_cap];
-    std::vector<uint32_t> e_src(g.nnz_local);   // source, encoded (segment << 29) | local row
-    std::vector<uint64_t> e_idx(g.nnz_local);   // original edge index (for the value)
+    const bool per_row_stream = geo.fr_blocks == 0;      // else the exact variant runs the blocked sweep too
+    std::vector<uint32_t> e_src(per_row_stream ? g.nnz_local : 0);   // source, encoded (segment << 29) | local row
+    std::vector<uint64_t> e_idx(per_row_stream ? g.nnz_local : 0);   // original edge index (for the value)
     // The same edges grouped by workgroup of the f64 blocked sweep, ascending by source.  The row
     // groups are handed out heaviest first, each to the workgroup with the fewest edges so far that
     // still has a free accumulator slot: a launch ends with its slowest workgroup, so edge counts
@@ -378,12 +407,13 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
             row_cut[t] = (uint32_t)(std::lower_bound(in_ptr.begin(), in_ptr.end(), g.nnz_local * t / T) - in_ptr.begin());
         for (unsigned t = 1; t <= T; ++t) row_cut[t] = std::max(row_cut[t], row_cut[t - 1]);
         row_cut[T] = geo.rows_cap;
-        scatter([&](uint32_t lr) { return (unsigned)(std::upper_bound(row_cut.begin() + 1, row_cut.end() - 1, lr) - (row_cut.begin() + 1)); },
-                [&](const Entry& e) {
-                    const uint64_t p = cur[e.lr]++;
-                    e_src[p] = e.pf;
-                    e_idx[p] = kept[e.k];
-                });
+        if (per_row_stream)
+            scatter([&](uint32_t lr) { return (unsigned)(std::upper_bound(row_cut.begin() + 1, row_cut.end() - 1, lr) - (row_cut.begin() + 1)); },
+                    [&](const Entry& e) {
+                        const uint64_t p = cur[e.lr]++;
+                        e_src[p] = e.pf;
+                        e_idx[p] = kept[e.k];
+                    });
         // (b) per-workgroup lists: thread t owns a contiguous range of workgroups
         const uint32_t B64 = geo.f64_blocks;
         std::vector<uint32_t> owner_of_block(B64, 0);
@@ -420,13 +450,22 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         }
     }
     // ---- 8. slices -----------------------------------------------------------------------------
+    g.n_dangling_local = 0;
+    {
+        const uint32_t active_local = geo.n_active_pad / G;       // local rows before the dangling class
+        for (uint32_t lr = active_local; lr < geo.rows_cap; ++lr) {
+            const uint64_t q = ((uint64_t)(lr >> 6) * G + seg_index) * 64 + (lr & 63);
+            if (q < (uint64_t)geo.n_active_pad + n_dangling) ++g.n_dangling_local;
+        }
+    }
+    if (geo.fr_blocks != 0) return ET_OK;   // the exact variant runs the blocked sweep: no per-row stream is needed
     const uint32_t long_row = opt.long_row ? opt.long_row : 128;
     const uint32_t n_local_slices = geo.rows_cap / 64;
     const uint32_t active_local_slices = geo.n_active_pad / 64 / G;
     std::vector<uint8_t> slice_dangling;
     uint64_t steps = 0;
     auto real_rows_in_slice = [&](uint32_t ls) -> uint32_t {
-        uint64_t q0 = ((uint64_t)ls * G + opt.seg) * 64;  // global row of lane 0
+        uint64_t q0 = ((uint64_t)ls * G + seg_index) * 64;  // global row of lane 0
         uint64_t end = ls < active_local_slices ? n_active : (uint64_t)geo.n_active_pad + n_dangling;
         if (q0 >= end) return 0;
         return (uint32_t)std::min<uint64_t>(64, end - q0);
@@ -471,8 +510,11 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         }
     }
     g.n_steps = steps;
-    g.n_dangling_local = 0;
-    for (uint32_t ls = active_local_slices; ls < n_local_slices; ++ls) g.n_dangling_local += real_rows_in_slice(ls);
+    {
+        uint32_t check = 0;
+        for (uint32_t ls = active_local_slices; ls < n_local_slices; ++ls) check += real_rows_in_slice(ls);
+        if (check != g.n_dangling_local) { err = "internal: dangling row count"; return ET_E_UNSUPPORTED; }
+    }
     // ---- 9. fill the edge stream -----------------------------------------------------------------
     const size_t slots = (size_t)steps * 64;
     g.col.assign(slots, 0);
@@ -528,6 +570,13 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
         return ET_E_UNSUPPORTED;
     }
     return ET_OK;
+}
+
+int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::string& err) {
+    PlanCommon pc;
+    int rc = plan_common(in, opt, pc, err);
+    if (rc) return rc;
+    return plan_segment(pc, opt, opt.seg, g, err);
 }
 
 }  // namespace et

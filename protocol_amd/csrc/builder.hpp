@@ -80,6 +80,19 @@ struct HostGraph {
 // Returns 0 or a negative ET_E_* code; `err` receives a human-readable reason.
 int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& out, std::string& err);
 
+// The same in two stages, for a caller that lays out every share of one graph: what does not depend on the share
+// (filter, dangling peers, order, positions, factors: steps 1-6) is computed once, then each share's edge lists.
+// The input arrays must stay alive until the last plan_segment call.
+struct PlanCommon {
+    BuildInput in;
+    HostGraph g;                        // geometry (seg = 0), positions, factors; no edge lists
+    std::vector<uint64_t> out_ptr, kept;
+    std::vector<uint8_t> drop, dangling;
+    std::vector<uint32_t> order;
+};
+int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& out, std::string& err);
+int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg, HostGraph& out, std::string& err);
+
 // host threads for the scatter passes over the edges (the GPU boxes give a process 16 CPUs)
 inline unsigned host_threads() {
     unsigned hw = std::thread::hardware_concurrency();

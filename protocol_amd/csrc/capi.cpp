@@ -50,6 +50,7 @@ const char* et_strerror(int code) {
         case ET_E_PARSE: return "malformed input";
         case ET_E_BAD_SIGNATURE: return "signature does not recover or verify";
         case ET_E_BAD_ABOUT: return "attestation is about another peer than its slot";
+        case ET_E_RCCL: return "RCCL error";
         default: return "unknown error";
     }
 }

@@ -156,6 +156,61 @@ class Graph:
         check(lib().et_graph_unpermute_f64_async(self._h, x_ptr, out_ptr, stream))
 
 
+class MultiGpuGraph:
+    """One graph row-sharded over several GPUs of this node, driven from this one process (et_sharded_*).
+    `devices` lists one HIP ordinal per share; the same ordinal twice rehearses the layout on fewer GPUs."""
+
+    def __init__(self, n, frm, to, value_u32=None, value_fr=None, member=None, devices=(0,),
+                 variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64, exchange=_ffi.ET_EXCHANGE_AUTO):
+        frm = np.ascontiguousarray(frm, dtype=np.uint32)
+        to = np.ascontiguousarray(to, dtype=np.uint32)
+        if len(frm) != len(to):
+            raise ValueError("from/to length mismatch")
+        if value_u32 is not None:
+            value_u32 = np.ascontiguousarray(value_u32, dtype=np.uint32)
+        if value_fr is not None:
+            value_fr = np.ascontiguousarray(value_fr, dtype=np.uint8)
+        if member is not None:
+            member = np.ascontiguousarray(member, dtype=np.uint8)
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        check(lib().et_sharded_create(n, _ptr(member), len(frm), _ptr(frm), _ptr(to), _ptr(value_u32), _ptr(value_fr),
+                                      len(devs), _ptr(devs), variants, exchange, C.byref(h)))
+        self._h = h
+        self.n = n
+        self.world = len(devs)
+        self.exchange = lib().et_sharded_exchange_kind(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().et_sharded_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self, share=0):
+        info = _ffi.EtGraphInfo()
+        check(lib().et_sharded_info_get(self._h, share, C.byref(info)))
+        return info
+
+    def converge_fr(self, num_iterations=20, initial=1000):
+        out = np.zeros((self.n, 32), dtype=np.uint8)
+        check(lib().et_sharded_converge_fr(self._h, num_iterations, initial & (2**64 - 1), initial >> 64, _ptr(out)))
+        return out
+
+    def converge_f64(self, num_iterations=20, initial=1000.0, alpha=0.0, pretrust=None):
+        out = np.zeros(self.n, dtype=np.float64)
+        res = C.c_double(0)
+        if pretrust is not None:
+            pretrust = np.ascontiguousarray(pretrust, dtype=np.float64)
+        check(lib().et_sharded_converge_f64(self._h, num_iterations, initial, alpha, _ptr(pretrust), _ptr(out), C.byref(res)))
+        return out, res.value
+
+
 class Plan:
     """Host-side layout of an attestation list (et_plan_*): what Graph uploads, without a GPU.
     Arrays are copied into numpy so they outlive the native object."""
