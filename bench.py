@@ -56,13 +56,13 @@ def algorithmic_bytes(variant, nnz, rows):
 
 
 def kernel_sources_sha():
-    """Identifies the kernels a counter record was taken on: hash of the sources the library is built from."""
+    """Identifies the kernels a counter record was taken on: hash of the step kernels' sources and of the layout
+    they run on."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "protocol_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".hpp", ".cpp")):
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
+    for name in ("engine.hip", "fr_dev.hpp", "layout.hpp", "builder.cpp"):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
 
 

@@ -15,6 +15,8 @@ It restates, with Python integers (mod r) and fractions.Fraction, exactly what
   EigenTrustSet.filter_peers_ops native.rs:234-283
   EigenTrustSet.converge         native.rs:286-337
   EigenTrustSet.converge_rational native.rs:340-392
+  circuit_converge               dynamic_sets/mod.rs:469-689, the halo2 circuit's statement of the
+                                 same filter / normalise / iterate, as a second, independent check
 
 Field arithmetic: the reference computes in halo2curves 0.3.2 `bn256::Fr`
 (Cargo.lock:1768-1770), which is absent from /root/reference.  Its results are observable
@@ -177,6 +179,54 @@ class EigenTrustSet:
                 new_s[i] = acc
             s = new_s
         return s
+
+
+def circuit_converge(set_addrs, ops, num_iterations, initial_score):
+    """The reference's SECOND statement of the same algorithm: what the halo2 circuit constrains
+    (eigentrust-zk/src/circuits/dynamic_sets/mod.rs:469-689), restated over plain field integers.
+    `set_addrs`: N slot addresses (0 = empty); `ops`: N x N opinion values, row i = slot i's opinions
+    (an empty slot's row is whatever the prover supplied; the circuit filters it like any other).
+
+    It differs from native.rs only where a slot is empty: the circuit filters and redistributes the
+    row of EVERY slot (mod.rs:469-600 loops over all i, so an empty slot's row sums to zero and
+    becomes ones over the occupied slots), seeds every slot with INITIAL_SCORE (mod.rs:642) and
+    fixes the total at INITIAL_SCORE * NUM_NEIGHBOURS (mod.rs:326-329, :674-689).  With every slot
+    occupied the two statements must agree on every score."""
+    n = len(set_addrs)
+    rows = []
+    for i in range(n):
+        addr_i = set_addrs[i]
+        ops_i = []
+        for j in range(n):
+            addr_j = set_addrs[j]
+            # mod.rs:479-512: nullified when set_addr_j == 0 or set_addr_j == addr_i
+            ops_i.append(0 if (addr_j == 0 or addr_j == addr_i) else fr(ops[i][j]))
+        total = 0
+        for v in ops_i:  # mod.rs:515-523
+            total = (total + v) % R_MODULUS
+        is_sum_zero = total == 0  # mod.rs:525-530
+        for j in range(n):  # mod.rs:532-592
+            addr_j = set_addrs[j]
+            if addr_j != addr_i and addr_j != 0 and is_sum_zero:
+                ops_i[j] = 1
+        rows.append(ops_i)
+    norm = []
+    for i in range(n):  # mod.rs:602-638
+        total = 0
+        for v in rows[i]:
+            total = (total + v) % R_MODULUS
+        inv = fr_inv(total)
+        norm.append([(v * inv) % R_MODULUS for v in rows[i]])
+    s = [fr(initial_score)] * n  # mod.rs:642
+    for _ in range(num_iterations):  # mod.rs:643-657
+        new_s = [0] * n
+        for i in range(n):
+            for j in range(n):
+                new_s[i] = (norm[j][i] * s[j] + new_s[i]) % R_MODULUS
+        s = new_s
+    # mod.rs:674-689: the sum of the scores is constrained to INITIAL_SCORE * NUM_NEIGHBOURS
+    assert sum(s) % R_MODULUS == fr(initial_score * n), "total reputation changed"
+    return s
 
 
 def rational_to_fr(q):

@@ -50,6 +50,34 @@ def test_python_oracle_reproduces_golden_and_invariants(scenarios):
                 assert ref.rational_to_fr(qi) == fi
 
 
+def test_circuit_statement_agrees_with_native_statement(scenarios):
+    """The reference checks its native converge against the circuit with MockProver
+    (dynamic_sets/mod.rs:744-868).  The circuit's constraints restated (circuit_converge) must give the native
+    scores wherever every slot is occupied; with an empty slot the two statements differ by design (the circuit
+    seeds and redistributes empty slots too) and the circuit's fixed total must still hold."""
+    full = 0
+    for sc in scenarios:
+        for s, exp in replay(sc):
+            addrs = [a for a, _ in s.set]
+            ops = [list(s.ops.get(a, [0] * s.n)) if a != 0 else [0] * s.n for a in addrs]
+            c = ref.circuit_converge(addrs, ops, s.num_iterations, s.initial_score)   # asserts the fixed total inside
+            if all(a != 0 for a in addrs):
+                assert [hex(v) for v in c] == exp["scores_fr"], sc["name"]
+                full += 1
+    assert full >= 3        # the reference's 10x10, 5x5 and 4x4 test matrices fill every slot
+    rng = random.Random(4)
+    for n in (2, 4, 7):     # random full sets, incl. all-zero rows and opinions about oneself
+        s = ref.EigenTrustSet(n, 12, 1000, 42)
+        addrs = [rng.randrange(1, R) for _ in range(n)]
+        for a in addrs:
+            s.add_member(a)
+        ops = [[rng.choice([0, 0, rng.randrange(256), rng.randrange(R)]) for _ in range(n)] for _ in range(n)]
+        ops[1] = [0] * n
+        for a, row in zip(addrs, ops):
+            s.update_op(a, row)
+        assert ref.circuit_converge(addrs, ops, 12, 1000) == s.converge()
+
+
 def test_known_peer_score_of_scaling_matrix(scenarios):
     sc = next(s for s in scenarios if s["name"] == "test_scaling_1")
     assert sc["checkpoints"][0]["scores_fr"][0] == "0x17942a6a1e6d480a143b3a2bc6cc20e49c4af5440c6d2da3db85036ae13cb096"

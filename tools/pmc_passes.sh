@@ -23,7 +23,7 @@ CGROUPS=(
 i=0
 for g in "${CGROUPS[@]}"; do
   d="$ROOT/gpurun_out/$OUT/pass$i"
-  timeout -s KILL 120 rocprofv3 --pmc $g --output-format csv -d "$d" -- python3 "$ROOT/bench.py" --variant "$VARIANT" --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$ROOT/gpurun_out/$OUT/pass$i.log" 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc $g --output-format csv -d "$d" -- python3 "$ROOT/bench.py" --variant "$VARIANT" --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > "$ROOT/gpurun_out/$OUT/pass$i.log" 2>&1
   rc=$?
   echo "pass $i rc=$rc : $g"
   if [ $rc -ne 0 ]; then tail -5 "$ROOT/gpurun_out/$OUT/pass$i.log"; exit $rc; fi
