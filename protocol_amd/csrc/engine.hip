@@ -244,9 +244,23 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
             for (int u = 0; u < U; ++u) atomicAdd(&acc_l[rc[u] & 0xFFFFu], w[u] * xv[u]);
             if (k & 1) __syncthreads();
         }
-        for (; e < e1; e += 1024, chunk += 16) {
-            const uint32_t rc = a.rec[e];
-            atomicAdd(&acc_l[rc & 0xFFFFu], (double)wr[e] * xr[(size_t)cb[chunk] + (rc >> 16)]);
+        {   // the rest of the list (fewer than U * 1024 edges) as one more batch, its loads in flight together like the
+            // others': taken 1024 at a time it was up to three more trips to memory, one after the other
+            uint32_t rc[U], base[U];
+            double w[U], xv[U];
+            bool in[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                in[u] = e + u * 1024 < e1;
+                rc[u] = in[u] ? a.rec[e + u * 1024] : 0u;
+                w[u] = in[u] ? (double)wr[e + u * 1024] : 0.0;
+                base[u] = in[u] ? cb[chunk + u * 16] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = in[u] ? xr[(size_t)base[u] + (rc[u] >> 16)] : 0.0;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (in[u]) atomicAdd(&acc_l[rc[u] & 0xFFFFu], w[u] * xv[u]);
         }
     } else {
         for (uint32_t k = 0; k < n_batches; ++k, e += U * 1024) {
@@ -261,10 +275,22 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
             for (int u = 0; u < U; ++u) atomicAdd(&acc_l[r[u]], w[u] * xv[u]);
             if (k & 1) __syncthreads();
         }
-        for (; e < e1; e += 1024) {
-            uint32_t c = a.col[e];
-            double xv = xr[(size_t)(c >> COL_SEG_SHIFT) * stride + (c & COL_LOCAL_MASK)];
-            atomicAdd(&acc_l[a.row[e]], (double)wr[e] * xv);
+        {   // the rest of the list as one more batch (see the packed form above)
+            uint32_t c[U], r[U];
+            double w[U], xv[U];
+            bool in[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                in[u] = e + u * 1024 < e1;
+                c[u] = in[u] ? a.col[e + u * 1024] : 0u;
+                w[u] = in[u] ? (double)wr[e + u * 1024] : 0.0;
+                r[u] = in[u] ? (uint32_t)a.row[e + u * 1024] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = in[u] ? xr[(size_t)(c[u] >> COL_SEG_SHIFT) * stride + (c[u] & COL_LOCAL_MASK)] : 0.0;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (in[u]) atomicAdd(&acc_l[r[u]], w[u] * xv[u]);
         }
     }
     __syncthreads();

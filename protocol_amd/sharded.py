@@ -22,7 +22,10 @@ from .graph import Graph, R_MODULUS
 
 class ShardedGraph:
     def __init__(self, n, frm, to, value_u32=None, value_fr=None, member=None, group=None,
-                 device=None, variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64, **build_kw):
+                 device=None, variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64, always_exchange=False, **build_kw):
+        # always_exchange: take the stepping + all-gather path even with a single rank (the collective is then a
+        # copy of the vector onto itself): the way to run the RCCL call of this driver on a one-GPU box
+        self.always_exchange = always_exchange
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -56,7 +59,7 @@ class ShardedGraph:
 
     def _all_gather(self, t):
         """In-place all-gather of the segments of `t`."""
-        if self.world == 1:
+        if self.world == 1 and not self.always_exchange:
             return
         backend = dist.get_backend(self.group)
         if backend == "nccl":
@@ -74,7 +77,7 @@ class ShardedGraph:
         """Enqueues a whole converge; the slot-order result stays on the device (result_f64)."""
         st = torch.cuda.current_stream(self.device).cuda_stream
         g = self.graph
-        if self.world == 1:  # no exchange step: the library's own back-to-back loop
+        if self.world == 1 and not self.always_exchange:  # no exchange step: the library's own back-to-back loop
             g.run_f64(num_iterations, initial, alpha, st, record)
             return
         x, y, out = self._buffers("f64")
@@ -100,7 +103,7 @@ class ShardedGraph:
     def run_fr(self, num_iterations=20, initial=1000, record=False):
         st = torch.cuda.current_stream(self.device).cuda_stream
         g = self.graph
-        if self.world == 1:
+        if self.world == 1 and not self.always_exchange:
             g.run_fr(num_iterations, initial, st, record)
             return
         x, y, out = self._buffers("fr")
@@ -119,13 +122,13 @@ class ShardedGraph:
 
     def result_f64(self):
         torch.cuda.synchronize(self.device)
-        if self.world == 1:
+        if self.world == 1 and not self.always_exchange:
             return self.graph.result_f64(torch.cuda.current_stream(self.device).cuda_stream)
         return self._buffers("f64")[2].cpu().numpy()
 
     def result_fr(self):
         torch.cuda.synchronize(self.device)
-        if self.world == 1:
+        if self.world == 1 and not self.always_exchange:
             return self.graph.result_fr(torch.cuda.current_stream(self.device).cuda_stream)
         return self._buffers("fr")[2].cpu().numpy().view(np.uint8).reshape(self.n, 32)
 
@@ -147,7 +150,7 @@ class ShardedGraph:
 
     def _sum_mod_r(self, mine):
         """Field sum over the ranks' partial sums: one gather of 32 bytes per rank."""
-        if self.world == 1:
+        if self.world == 1 and not self.always_exchange:
             return mine % R_MODULUS
         dev = self.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
         words = np.frombuffer(int(mine % R_MODULUS).to_bytes(32, "little"), dtype=np.int64).copy()

@@ -126,3 +126,45 @@ def test_all_shares_in_one_process(world):
         else:
             got = out.cpu().numpy().astype(np.longdouble)
             assert float(np.abs(got - eld).sum() / np.abs(eld).sum()) <= 1e-9
+
+
+def _nccl_worker(rank, world, port, case, ret):
+    import torch
+    import torch.distributed as dist
+    from protocol_amd.sharded import ShardedGraph
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    n, member, frm, to, val, iters = case
+    sg = ShardedGraph(n, frm, to, value_u32=val, member=member, device=dev, always_exchange=True)
+    ret["fr"] = sg.converge_fr(iters, 1000).tobytes()      # conservation checked through the 32-byte tensor gather
+    ret["f64"] = sg.converge_f64(iters, 1000.0).tolist()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_with_the_one_rank_a_single_gpu_allows():
+    """The driver's RCCL calls themselves (in-place all_gather_into_tensor of the segments, the 32-byte gather of the
+    conservation check) with backend nccl: one rank is all a single GPU allows, so the collective copies the vector
+    onto itself, but it is the same call, on the same tensors, that N ranks make."""
+    import c_oracle
+    import protocol_amd as pa
+    n = 40000
+    frm, to, val = pa.synth_graph(3, n, 16 * n, seed=11, value_max=255)
+    member = np.ones(n, dtype=np.uint8)
+    member[::53] = 0
+    iters = 6
+    rc, exp, _nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000)
+    assert rc == 0
+    rc, _e64, eld, _r, _n, _s = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=iters,
+                                                             initial=1000.0, want_ld=True)
+    assert rc == 0
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() + 7) % 2000
+    mp.spawn(_nccl_worker, args=(1, port, (n, member, frm, to, val, iters), ret), nprocs=1, join=True)
+    assert ret["fr"] == exp.tobytes()
+    got = np.array(ret["f64"], dtype=np.longdouble)
+    assert float(np.abs(got - eld).sum() / np.abs(eld).sum()) <= 1e-9
