@@ -810,20 +810,32 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
         atomicAdd(p + 6 * RB, (unsigned long long)hi.z * v);
         atomicAdd(p + 7 * RB, (unsigned long long)hi.w * v);
     };
-    for (uint32_t k = 0; k < n_batches; ++k, e += U * 1024) {
+    {
+        // the records of batch k+1 are asked for before the gathers of batch k are used: a record comes from memory
+        // and the gather's address from the record, so the two trips of a batch would otherwise follow each other
         uint32_t c[U], v[U], r[U];
-        uint4 lo[U], hi[U];
+        if (n_batches) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) { c[u] = a.col[e + u * 1024]; v[u] = a.val[e + u * 1024]; r[u] = a.row[e + u * 1024]; }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint4* p = a.x + 2 * ((size_t)(c[u] >> COL_SEG_SHIFT) * stride + (c[u] & COL_LOCAL_MASK));
-            lo[u] = p[0];
-            hi[u] = p[1];
+            for (int u = 0; u < U; ++u) { c[u] = a.col[e + u * 1024]; v[u] = a.val[e + u * 1024]; r[u] = a.row[e + u * 1024]; }
         }
+        for (uint32_t k = 0; k < n_batches; ++k, e += U * 1024) {
+            uint4 lo[U], hi[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) add_edge(r[u], v[u], lo[u], hi[u]);
-        if (k & 1) __syncthreads();
+            for (int u = 0; u < U; ++u) {
+                const uint4* p = a.x + 2 * ((size_t)(c[u] >> COL_SEG_SHIFT) * stride + (c[u] & COL_LOCAL_MASK));
+                lo[u] = p[0];
+                hi[u] = p[1];
+            }
+            uint32_t cn[U], vn[U], rn[U];
+            const uint64_t en = k + 1 < n_batches ? e + U * 1024 : e;      // the last pass reads its own records again
+#pragma unroll
+            for (int u = 0; u < U; ++u) { cn[u] = a.col[en + u * 1024]; vn[u] = a.val[en + u * 1024]; rn[u] = a.row[en + u * 1024]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) add_edge(r[u], v[u], lo[u], hi[u]);
+            if (k & 1) __syncthreads();
+#pragma unroll
+            for (int u = 0; u < U; ++u) { c[u] = cn[u]; v[u] = vn[u]; r[u] = rn[u]; }
+        }
     }
     {   // the rest of the list as one more batch, its loads in flight together like the others'
         uint32_t c[U], v[U], r[U];
