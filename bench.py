@@ -233,7 +233,7 @@ def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu):
     t_gen = time.time() - t0
     variants = {"both": 3, "fr": 1, "f64": 2}[args.variant]
     t0 = time.time()
-    sg = ShardedGraph(n, frm, to, value_u32=val, device=device, variants=variants)
+    sg = ShardedGraph(n, frm, to, value_u32=val, device=device, variants=variants, n_chunks=args.chunks)
     t_build = time.time() - t0
     info = sg.graph.info
     nnz = int(info.nnz)
@@ -284,9 +284,10 @@ def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         ev_ms, ev_pairs = sg.graph.event_times()
-        launches = ev_pairs * (NUM_ITER if world == 1 else 1)
+        launches = ev_pairs * NUM_ITER if world == 1 else ev_pairs / max(1, sg.n_chunks)
         # world == 1 brackets the 20 back-to-back launches of a step with one pair of events;
-        # the sharded loop brackets every launch (an all-gather sits between launches)
+        # the sharded loop brackets every launch (an all-gather sits between launches; with a chunked exchange an
+        # iteration is n_chunks launches, counted as one)
         launch_s = ev_ms * 1e-3 / max(1, launches)
         rows_local = int(info.n_valid) // world
         alg = algorithmic_bytes(variant, int(info.nnz_local), rows_local)
@@ -370,7 +371,7 @@ def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu):
         "dtype": "f64" if "f64" in results else "fr254", "data": "synthetic",
         "config": {"workload": "%s: %s; %d iterations per step; byte opinions kept raw in the edge records" % (wl, desc, NUM_ITER),
                    "peers": n, "edges": nnz, "iterations": NUM_ITER, "parallelism": "rows sharded x%d" % world,
-                   "seed": args.seed},
+                   "exchange_pieces": sg.n_chunks, "seed": args.seed},
         "roofline": head["roofline"],
         "cpu_baseline": cpu,
         "checks": checks,
@@ -391,6 +392,7 @@ def main():
     ap.add_argument("--variant", default="both", choices=["both", "f64", "fr"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="N = 1, workload auto: only the 1M-peer graph, not the other configurations")
+    ap.add_argument("--chunks", type=int, default=1, help="N > 1: exchange a segment in this many pieces beside the iteration's launches (1 = one all-gather per iteration)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--c5-sets", type=int, default=C5_SETS, help="small-set workload: number of sets")
     ap.add_argument("--c5-slots", type=int, default=C5_SLOTS, help="small-set workload: slots per set (<= 1024)")

@@ -78,6 +78,7 @@ pub struct et_build_opts {
     pub target_work: u32,
     pub variants: u32,
     pub device: i32,
+    pub n_chunks: u32,
 }
 
 #[repr(C)]
@@ -99,6 +100,8 @@ pub struct et_graph_info {
     pub device_bytes: u64,
     pub f64_sweep_blocks: u32,
     pub exact_sweep_blocks: u32,
+    pub n_chunks: u32,
+    pub chunk_rows: u32,
 }
 
 #[repr(C)]
@@ -219,6 +222,10 @@ extern "C" {
                                   stream: *mut c_void) -> c_int;
     pub fn et_graph_step_f64_async(g: *mut et_graph, x: *const c_void, y: *mut c_void, iteration: u32, alpha: f64,
                                    pretrust_pos: *const c_void, flags: u32, stream: *mut c_void) -> c_int;
+    pub fn et_graph_step_fr_phase_async(g: *mut et_graph, x: *const c_void, y: *mut c_void, iteration: u32, flags: u32,
+                                        phase: u32, stream: *mut c_void) -> c_int;
+    pub fn et_graph_step_f64_phase_async(g: *mut et_graph, x: *const c_void, y: *mut c_void, iteration: u32, alpha: f64,
+                                         pretrust_pos: *const c_void, flags: u32, phase: u32, stream: *mut c_void) -> c_int;
     pub fn et_graph_unpermute_fr_async(g: *mut et_graph, x: *const c_void, out_slots: *mut c_void,
                                        stream: *mut c_void) -> c_int;
     pub fn et_graph_unpermute_f64_async(g: *mut et_graph, x: *const c_void, out_slots: *mut c_void,
@@ -253,7 +260,7 @@ extern "C" {
     /// Row-sharded converge over the GPUs of one node from one host thread (RCCL all-gather or device copies).
     pub fn et_sharded_create(n: u32, member: *const u8, n_edges: u64, from: *const u32, to: *const u32,
                              value_u32: *const u32, value_fr: *const et_fr, n_devices: u32, devices: *const i32,
-                             variants: u32, exchange: u32, out: *mut *mut et_sharded) -> c_int;
+                             variants: u32, exchange: u32, n_chunks: u32, out: *mut *mut et_sharded) -> c_int;
     pub fn et_sharded_free(s: *mut et_sharded);
     pub fn et_sharded_exchange_kind(s: *const et_sharded) -> c_int;
     pub fn et_sharded_info_get(s: *const et_sharded, share: u32, info: *mut et_graph_info) -> c_int;

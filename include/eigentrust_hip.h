@@ -134,6 +134,10 @@ typedef struct {
     uint32_t target_work; /* 0 = default; wavefront work items per launch                      */
     uint32_t variants;      /* ET_VARIANT_* bit mask; 0 = both                                   */
     int32_t device;         /* HIP device ordinal; -1 = current device                           */
+    uint32_t n_chunks;      /* 0 / 1 = off; K > 1: a segment is exchanged in K pieces and an iteration
+                               runs as K launches (et_graph_step_*_phase_async), so that the exchange of
+                               piece q + 1 can run beside the launch over piece q.  Honoured where both
+                               variants run the blocked sweep (see et_graph_info.n_chunks)               */
 } et_build_opts;
 
 typedef struct {
@@ -151,6 +155,9 @@ typedef struct {
     uint32_t f64_sweep_blocks;   /* workgroups of the f64 blocked sweep (0: variant not prepared)     */
     uint32_t exact_sweep_blocks; /* workgroups of the exact blocked sweep; 0: the exact variant runs
                                     its row-per-lane kernel on this graph                             */
+    uint32_t n_chunks;      /* pieces a segment is exchanged in (1 = whole)                            */
+    uint32_t chunk_rows;    /* piece q of a segment = its entries [q*chunk_rows, (q+1)*chunk_rows); the
+                               last piece runs to the end of the segment (rows_cap + nd_cap)            */
 } et_graph_info;
 
 /* Filter + normalise + lay out an attestation list (see et_set_update_op for the meaning of a
@@ -223,6 +230,15 @@ int et_graph_step_fr_async(et_graph *g, const void *x, void *y, uint32_t iterati
                            void *stream);
 int et_graph_step_f64_async(et_graph *g, const void *x, void *y, uint32_t iteration, double alpha,
                             const void *pretrust_pos, uint32_t flags, void *stream);
+/* One of the n_chunks launches of an iteration (graphs built with et_build_opts.n_chunks > 1): launch
+ * `phase` reads only the entries of x in piece `phase` of every segment, so it may be enqueued as soon as those
+ * have arrived; the launches of one iteration run in order 0 .. n_chunks-1 on one stream, the last one writes
+ * this share's segment of y.  (et_graph_step_*_async on such a graph enqueues all of them.) */
+int et_graph_step_fr_phase_async(et_graph *g, const void *x, void *y, uint32_t iteration,
+                                 uint32_t flags, uint32_t phase, void *stream);
+int et_graph_step_f64_phase_async(et_graph *g, const void *x, void *y, uint32_t iteration, double alpha,
+                                  const void *pretrust_pos, uint32_t flags, uint32_t phase,
+                                  void *stream);
 /* Position order -> slot order (device to device): out has n entries. */
 int et_graph_unpermute_fr_async(et_graph *g, const void *x, void *out_slots, void *stream);
 int et_graph_unpermute_f64_async(et_graph *g, const void *x, void *out_slots, void *stream);
@@ -266,6 +282,9 @@ int et_graph_result_f64(et_graph *g, double *out, void *stream);
  *   devices  : n_devices HIP ordinals.  Listing a device more than once rehearses the N-share layout on
  *              fewer GPUs (exchange by copies: RCCL refuses two ranks of a communicator on one device).
  *   exchange : ET_EXCHANGE_AUTO = RCCL when the devices are distinct and librccl loads, else copies.
+ *   n_chunks : 0 / 1 = one exchange after each iteration's launch; K > 1 = the segments travel in K pieces on
+ *              a second stream per share while the iteration's K launches run, launch q waiting only for
+ *              piece q (see et_build_opts.n_chunks).
  * Errors: those of et_graph_build, ET_E_RCCL, ET_E_SUM_MISMATCH (native.rs:334).
  * ---------------------------------------------------------------------------------------- */
 typedef struct et_sharded et_sharded;
@@ -273,7 +292,7 @@ enum { ET_EXCHANGE_AUTO = 0, ET_EXCHANGE_RCCL = 1, ET_EXCHANGE_COPY = 2 };
 int et_sharded_create(uint32_t n, const uint8_t *member, uint64_t n_edges, const uint32_t *from,
                       const uint32_t *to, const uint32_t *value_u32, const et_fr *value_fr,
                       uint32_t n_devices, const int32_t *devices, uint32_t variants, uint32_t exchange,
-                      et_sharded **out);
+                      uint32_t n_chunks, et_sharded **out);
 void et_sharded_free(et_sharded *s);
 /* ET_EXCHANGE_RCCL or ET_EXCHANGE_COPY: what et_sharded_create settled on. */
 int et_sharded_exchange_kind(const et_sharded *s);

@@ -44,7 +44,8 @@ class EtFr(C.Structure):
 
 class EtBuildOpts(C.Structure):
     _fields_ = [("n_seg", C.c_uint32), ("seg", C.c_uint32), ("long_row", C.c_uint32),
-                ("target_work", C.c_uint32), ("variants", C.c_uint32), ("device", C.c_int32)]
+                ("target_work", C.c_uint32), ("variants", C.c_uint32), ("device", C.c_int32),
+                ("n_chunks", C.c_uint32)]
 
 
 class EtGraphInfo(C.Structure):
@@ -54,7 +55,8 @@ class EtGraphInfo(C.Structure):
                 ("n_slices", C.c_uint32), ("n_work", C.c_uint32),
                 ("rows_cap", C.c_uint32), ("nd_cap", C.c_uint32),
                 ("vec_len", C.c_uint64), ("device_bytes", C.c_uint64),
-                ("f64_sweep_blocks", C.c_uint32), ("exact_sweep_blocks", C.c_uint32)]
+                ("f64_sweep_blocks", C.c_uint32), ("exact_sweep_blocks", C.c_uint32),
+                ("n_chunks", C.c_uint32), ("chunk_rows", C.c_uint32)]
 
 
 class EtSliceDesc(C.Structure):
@@ -126,6 +128,8 @@ PROTOTYPES = {
     "et_graph_init_f64_async": (i32, [vp, dbl, vp, u32, vp]),
     "et_graph_step_fr_async": (i32, [vp, vp, vp, u32, u32, vp]),
     "et_graph_step_f64_async": (i32, [vp, vp, vp, u32, dbl, vp, u32, vp]),
+    "et_graph_step_fr_phase_async": (i32, [vp, vp, vp, u32, u32, u32, vp]),
+    "et_graph_step_f64_phase_async": (i32, [vp, vp, vp, u32, dbl, vp, u32, u32, vp]),
     "et_graph_unpermute_fr_async": (i32, [vp, vp, vp, vp]),
     "et_graph_unpermute_f64_async": (i32, [vp, vp, vp, vp]),
     "et_graph_permute_f64_host": (i32, [vp, vp, vp]),
@@ -138,7 +142,7 @@ PROTOTYPES = {
     "et_graph_event_times": (i32, [vp, P(C.c_float), P(u32)]),
     "et_graph_result_fr": (i32, [vp, vp, vp]),
     "et_graph_result_f64": (i32, [vp, vp, vp]),
-    "et_sharded_create": (i32, [u32, vp, u64, vp, vp, vp, vp, u32, vp, u32, u32, P(vp)]),
+    "et_sharded_create": (i32, [u32, vp, u64, vp, vp, vp, vp, u32, vp, u32, u32, u32, P(vp)]),
     "et_sharded_free": (None, [vp]),
     "et_sharded_exchange_kind": (i32, [vp]),
     "et_sharded_info_get": (i32, [vp, u32, P(EtGraphInfo)]),

@@ -221,6 +221,13 @@ int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& pc, std:
             geo.nd_cap = std::max<uint32_t>(geo.nd_cap, (geo.fr_dblocks + 15) / 16 * 16);
         }
     }
+    geo.n_chunks = 1;
+    geo.chunk_rows = geo.rows_cap;
+    if (opt.n_chunks > 1 && geo.fr_blocks != 0) {
+        const uint32_t K = std::min<uint32_t>(opt.n_chunks, 8);
+        const uint32_t cr = round_up((geo.rows_cap + K - 1) / K, 64);
+        if ((uint64_t)(K - 1) * cr < geo.rows_cap) { geo.n_chunks = K; geo.chunk_rows = cr; }
+    }
     g.geo = geo;
     if (G > 8 || geo.seg_stride() >= COL_LOCAL_MASK) {
         err = "more than 8 segments or more than 2^29 rows per segment";
@@ -360,7 +367,12 @@ int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index,
         std::vector<uint64_t> cur(in_ptr.begin(), in_ptr.end() - 1);
         std::vector<uint64_t> bcur(g.bk_ptr.begin(), g.bk_ptr.end() - 1);
         std::vector<uint32_t> by_pos(order.begin(), order.begin() + n_active);
-        std::sort(by_pos.begin(), by_pos.end(), [&](uint32_t a, uint32_t b) { return g.pos_of_ext[a] < g.pos_of_ext[b]; });
+        // ascending position; with a chunked exchange, piece by piece (piece q of every segment before piece q + 1 of any)
+        auto visit_key = [&](uint32_t ext) -> uint64_t {
+            const uint32_t p = g.pos_of_ext[ext];
+            return ((uint64_t)(geo.n_chunks > 1 ? geo.chunk_of_local(p % geo.seg_stride()) : 0u) << 32) | p;
+        };
+        std::sort(by_pos.begin(), by_pos.end(), [&](uint32_t a, uint32_t b) { return visit_key(a) < visit_key(b); });
         // Every thread walks ONE contiguous chunk of the attesters (ascending position, chunks of equal edge count)
         // and drops each surviving edge into the bucket of the thread that owns its destination; a bucket therefore
         // holds its edges in ascending source order, and its owner appends them to the rows (or workgroups) it owns.
@@ -448,6 +460,21 @@ int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index,
                         g.fb_val[q] = (uint8_t)in.val_u32[kept[e.k]];
                     });
         }
+    }
+    if (geo.n_chunks > 1) {
+        // a list is sorted by piece: the runs' boundaries by binary search on the piece of an entry's source
+        auto runs = [&](const std::vector<uint64_t>& ptr, const std::vector<uint32_t>& col, uint32_t B, std::vector<uint64_t>& out) {
+            const uint32_t K = geo.n_chunks;
+            out.assign((size_t)B * (K + 1), 0);
+            for (uint32_t b = 0; b < B; ++b) {
+                const uint32_t* lo = col.data() + ptr[b];
+                const uint32_t* hi = col.data() + ptr[b + 1];
+                for (uint32_t q = 0; q <= K; ++q)
+                    out[(size_t)b * (K + 1) + q] = ptr[b] + (std::partition_point(lo, hi, [&](uint32_t c) { return geo.chunk_of_local(c & COL_LOCAL_MASK) < q; }) - lo);
+            }
+        };
+        runs(g.bk_ptr, g.bk_col, geo.f64_blocks, g.bk_phase);
+        runs(g.fb_ptr, g.fb_col, geo.fr_blocks, g.fb_phase);
     }
     // ---- 8. slices -----------------------------------------------------------------------------
     g.n_dangling_local = 0;

@@ -40,6 +40,7 @@ struct BuildOpts {
     uint32_t target_work = 16384; // wavefront work items per iteration launch (several rounds of 256 CUs x 16 waves)
     uint32_t hot_prefix = 16384; // the most-attesting (most gathered) peers take the first positions: one contiguous prefix of the vector
     uint32_t f64_blocks = 256;   // workgroups of the f64 variant (one per CU)
+    uint32_t n_chunks = 1;       // pieces a segment is exchanged in (see Geometry::n_chunks); honoured where both variants run the blocked sweep
 };
 
 struct HostGraph {
@@ -69,6 +70,9 @@ struct HostGraph {
     std::vector<uint32_t> fb_grp, fb_col;
     std::vector<uint16_t> fb_row;
     std::vector<uint8_t> fb_val;
+    // chunked exchange: [workgroup][n_chunks + 1] absolute indices into the lists above, run q = edges whose source
+    // lies in piece q (empty when n_chunks == 1)
+    std::vector<uint64_t> bk_phase, fb_phase;
     std::vector<FrRaw> bk_val_fr;
     // Per-position source factors (zero for dangling / non-member / padding positions):
     std::vector<FrRaw> scale_fr;        // inv(row sum) * 2^576 mod r

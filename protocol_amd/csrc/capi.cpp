@@ -55,7 +55,7 @@ const char* et_strerror(int code) {
     }
 }
 const char* et_last_error_message(void) { return last_error(); }
-uint32_t et_abi_version(void) { return (0u << 16) | 1u; }
+uint32_t et_abi_version(void) { return (0u << 16) | 2u; }
 int et_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -78,6 +78,7 @@ static void read_opts(const et_build_opts* opts, BuildOpts& bo, int& variants, i
     if (opts->target_work) bo.target_work = opts->target_work;
     variants = (int)opts->variants;
     device = opts->device;
+    if (opts->n_chunks) bo.n_chunks = opts->n_chunks;
 }
 
 // Tuning knobs for experiments (not part of the ABI): ET_TARGET_WORK, ET_LONG_ROW, ET_F64_BLOCKS, ET_HOT_PREFIX.
@@ -122,6 +123,7 @@ static void fill_info(const HostGraph& h, et_graph_info* info) {
     info->n_slices = (uint32_t)h.slices.size(); info->n_work = (uint32_t)h.work.size();
     info->rows_cap = h.geo.rows_cap; info->nd_cap = h.geo.nd_cap;
     info->vec_len = (uint64_t)h.geo.n_seg * h.geo.seg_stride();
+    info->n_chunks = h.geo.n_chunks; info->chunk_rows = h.geo.chunk_rows;
 }
 int et_plan_info_get(const et_plan* p, et_graph_info* info) {
     if (!p || !info) return ET_E_INVALID_ARG;
@@ -179,6 +181,7 @@ int et_graph_info_get(const et_graph* g, et_graph_info* info) {
     info->vec_len = d->vec_len; info->device_bytes = d->device_bytes;
     info->f64_sweep_blocks = d->n_f64_parts;
     info->exact_sweep_blocks = d->fr_blocked ? d->geo.fr_blocks : 0;
+    info->n_chunks = d->geo.n_chunks; info->chunk_rows = d->geo.chunk_rows;
     return ET_OK;
 }
 
@@ -256,6 +259,17 @@ int et_graph_step_f64_async(et_graph* g, const void* x, void* y, uint32_t iterat
     if (!g || !x || !y) return ET_E_INVALID_ARG;
     HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->step_f64((const double*)x, (double*)y, iteration, alpha, (const double*)pretrust_pos, flags, (hipStream_t)stream);
+}
+int et_graph_step_fr_phase_async(et_graph* g, const void* x, void* y, uint32_t iteration, uint32_t flags, uint32_t phase, void* stream) {
+    if (!g || !x || !y) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
+    return G(g)->step_fr((const uint4*)x, (uint4*)y, iteration, flags, (hipStream_t)stream, (int)phase);
+}
+int et_graph_step_f64_phase_async(et_graph* g, const void* x, void* y, uint32_t iteration, double alpha,
+                                  const void* pretrust_pos, uint32_t flags, uint32_t phase, void* stream) {
+    if (!g || !x || !y) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
+    return G(g)->step_f64((const double*)x, (double*)y, iteration, alpha, (const double*)pretrust_pos, flags, (hipStream_t)stream, (int)phase);
 }
 int et_graph_unpermute_fr_async(et_graph* g, const void* x, void* out_slots, void* stream) {
     if (!g || !x || !out_slots) return ET_E_INVALID_ARG;

@@ -166,6 +166,11 @@ struct StepArgsF64B {
     double inv_nm1;
     double alpha;
     uint32_t final_step;
+    // chunked exchange: this launch is run `phase` of `n_phases` over the workgroup's list (phase_ptr[b][n_phases + 1]);
+    // the rows' partial sums travel between the launches of one iteration in acc_g[b][f64_rb].  n_phases == 1: one launch.
+    const uint64_t* phase_ptr;
+    double* acc_g;
+    uint32_t phase, n_phases;
 };
 
 template <typename VT, bool HAS_ALPHA, bool PACKED = false>
@@ -182,14 +187,15 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     const size_t my_base = (size_t)a.geo.seg * stride;
     const double* __restrict__ xr = a.x;
     const VT* __restrict__ wr = static_cast<const VT*>(a.w);
-    for (uint32_t i = threadIdx.x; i < RB; i += 1024) acc_l[i] = 0.0;
+    const bool first_phase = a.phase == 0, last_phase = a.phase + 1 == a.n_phases;
+    for (uint32_t i = threadIdx.x; i < RB; i += 1024) acc_l[i] = first_phase ? 0.0 : a.acc_g[(size_t)b * RB + i];
     // the step owns the whole partial-sum tail of its segment of y: slots no workgroup writes are set to zero, so the
     // next step's sum over all nd_cap slots never reads what the caller's allocation happened to hold
-    if (b == 0)
+    if (b == 0 && last_phase)
         for (uint32_t k = a.geo.f64_dblocks + threadIdx.x; k < a.geo.nd_cap; k += 1024) a.y[my_base + a.geo.rows_cap + k] = 0.0;
     // score mass of dangling peers: fixed-order sum of every segment's partial sums.  Only the rows' epilogue needs
     // it: the first four entries per lane are requested here and added after the sweep, so their latency is hidden
-    const uint32_t d_total = a.geo.n_dangling != 0 ? a.geo.n_seg * a.geo.nd_cap : 0u;
+    const uint32_t d_total = a.geo.n_dangling != 0 && last_phase ? a.geo.n_seg * a.geo.nd_cap : 0u;
     double dv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const uint32_t lr = threadIdx.x + u * 1024;
-        pgrp[u] = lr < RB ? a.grp[(size_t)b * (RB / BLOCK_GROUP) + lr / BLOCK_GROUP] : 0xFFFFFFFFu;
+        pgrp[u] = lr < RB && last_phase ? a.grp[(size_t)b * (RB / BLOCK_GROUP) + lr / BLOCK_GROUP] : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -223,7 +229,8 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     }
     __syncthreads();
 
-    const uint64_t e0 = a.bk_ptr[b], e1 = a.bk_ptr[b + 1];
+    const uint64_t e0 = a.n_phases > 1 ? a.phase_ptr[(size_t)b * (a.n_phases + 1) + a.phase] : a.bk_ptr[b];
+    const uint64_t e1 = a.n_phases > 1 ? a.phase_ptr[(size_t)b * (a.n_phases + 1) + a.phase + 1] : a.bk_ptr[b + 1];
     constexpr int U = 4;
     // Full batches of U * 1024 edges, the same number for every thread.  The hardware favours the
     // oldest wavefront of a workgroup, which lets it run far ahead of the youngest; a barrier every
@@ -294,6 +301,10 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
         }
     }
     __syncthreads();
+    if (!last_phase) {                                     // the partial sums wait for the next launch of this iteration
+        for (uint32_t i = threadIdx.x; i < RB; i += 1024) a.acc_g[(size_t)b * RB + i] = acc_l[i];
+        return;
+    }
 
     double D = (dv[0] + dv[1]) + (dv[2] + dv[3]);
     for (uint32_t t = lane + 256; t < d_total; t += 64) {
@@ -699,7 +710,11 @@ struct StepArgsFrB {
     uint32_t* chg_part;       // [fr_blocks]
     Geometry geo;
     uint32_t final_step;
-    uint32_t debug;           // measurement only: bit 0 skips the sweep, bit 1 the rows (results are then wrong)
+    // chunked exchange: run `phase` of `n_phases` over the workgroup's list (phase_ptr[b][n_phases + 1]); the rows'
+    // unreduced sums travel between the launches of one iteration in acc_g[b][LDS image].  n_phases == 1: one launch.
+    const uint64_t* phase_ptr;
+    unsigned long long* acc_g;
+    uint32_t phase, n_phases;
     U256 inv_nm1_w;
     U256 inv_nm1_w576;        // inv(n_valid - 1) * 2^576
 };
@@ -735,17 +750,15 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     const uint32_t stride = a.geo.seg_stride();
     const size_t my_base = (size_t)a.geo.seg * stride;
     uint32_t* const top_l = reinterpret_cast<uint32_t*>(colsum_l + 4 * (size_t)RB);   // COMPACT: limb 8 of every row
-    if (COMPACT) {
-        for (uint32_t i = threadIdx.x; i < 4 * RB + RB / 2; i += 1024) colsum_l[i] = 0;   // RB is a multiple of 16
-    } else {
-        for (uint32_t i = threadIdx.x; i < 8 * RB; i += 1024) colsum_l[i] = 0;
-    }
+    const bool first_phase = a.phase == 0, last_phase = a.phase + 1 == a.n_phases;
+    const uint32_t lds_words = COMPACT ? 4 * RB + RB / 2 : 8 * RB;                     // RB is a multiple of 16
+    for (uint32_t i = threadIdx.x; i < lds_words; i += 1024) colsum_l[i] = first_phase ? 0ull : a.acc_g[(size_t)b * lds_words + i];
     // partial-sum slots no workgroup writes: zero, whatever the caller's buffer held (see fr_zero_unused_tail)
-    fr_zero_unused_tail(a.y, a.geo, a.geo.fr_dblocks, 1024);
+    if (last_phase) fr_zero_unused_tail(a.y, a.geo, a.geo.fr_dblocks, 1024);
     __syncthreads();
     // the first wavefront prepares the dangling term while the others already sweep; the workgroup next meets at
     // the sweep's own barriers, and the term is read after the barrier that ends the sweep
-    if (wave == 0) {
+    if (wave == 0 && last_phase) {
         // the product with inv(n_valid - 1) * 2^576, reduced once: inv(n_valid - 1) * D * 2^288 below r
         fr_dangling_mass(a.x, a.geo, a.inv_nm1_w576, lane, sh_d, sh_pd);
         if (lane == 0) {
@@ -758,13 +771,13 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
         }
     }
 
-    const uint64_t e0 = a.ptr[b], e1 = a.ptr[b + 1];
+    const uint64_t e0 = a.n_phases > 1 ? a.phase_ptr[(size_t)b * (a.n_phases + 1) + a.phase] : a.ptr[b];
+    const uint64_t e1 = a.n_phases > 1 ? a.phase_ptr[(size_t)b * (a.n_phases + 1) + a.phase + 1] : a.ptr[b + 1];
     // three edges per thread in flight and a barrier every second batch: 145 us on the 1M-peer benchmark graph against
     // 153 us for four (150 us for two, 156 us without the barriers' help or with a barrier every batch)
     constexpr int U = 3;
-    uint32_t n_batches = (uint32_t)((e1 - e0) / (U * 1024));
+    const uint32_t n_batches = (uint32_t)((e1 - e0) / (U * 1024));
     uint64_t e = e0 + threadIdx.x;
-    if (a.debug & 1u) { n_batches = 0; e = e1; }
     // a carry into word k of a row (k = 1..3), or into the top limb (k = 4)
     auto carry_into = [&](uint32_t slot, uint32_t k) {
         for (; k < 4; ++k)
@@ -859,6 +872,10 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             if (e + u * 1024 < e1) add_edge(r[u], v[u], lo[u], hi[u]);
     }
     __syncthreads();
+    if (!last_phase) {                                    // the unreduced sums wait for the next launch of this iteration
+        for (uint32_t i = threadIdx.x; i < lds_words; i += 1024) a.acc_g[(size_t)b * lds_words + i] = colsum_l[i];
+        return;
+    }
 
     U256 dacc = u256_zero();                              // field sum of this thread's dangling rows' scores
     Acc10 traw = acc10_zero();                            // integer sum of this thread's T
@@ -889,7 +906,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     };
     // rows with opinions first (the common case, no dangling arithmetic in the loop), then the dangling rows, which
     // only the leading workgroups hold
-    for (uint32_t lr = threadIdx.x; lr < ((a.debug & 2u) ? 0u : RB); lr += 1024) {
+    for (uint32_t lr = threadIdx.x; lr < RB; lr += 1024) {
         const uint32_t grp = a.grp[(size_t)b * (RB / BLOCK_GROUP) + lr / BLOCK_GROUP];
         if (grp == 0xFFFFFFFFu) continue;
         const uint32_t row = grp * BLOCK_GROUP + lr % BLOCK_GROUP;
@@ -1062,7 +1079,7 @@ static int dev_upload(T** p, const std::vector<T>& v, uint64_t& total) {
 DeviceGraph::~DeviceGraph() {
     if (device >= 0) (void)hipSetDevice(device);
     void* ptrs[] = {d_bk_ptr, d_bk_grp, d_bk_col, d_bk_row, d_bk_w, d_bk_rec, d_bk_cbase, d_bk_cptr, d_fb_ptr, d_fb_grp, d_fb_col, d_fb_row, d_fb_val, d_work, d_slices, d_col, d_val, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
-                    d_chg_part, d_stat_out, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust, d_scale64, d_scale_fr, d_fb_scale, own64, own_fr};
+                    d_chg_part, d_stat_out, d_bk_phase, d_fb_phase, d_f64_acc, d_fr_acc, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust, d_scale64, d_scale_fr, d_fb_scale, own64, own_fr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* e : ev_begin) (void)hipEventDestroy((hipEvent_t)e);
     for (void* e : ev_end) (void)hipEventDestroy((hipEvent_t)e);
@@ -1132,7 +1149,8 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
         if ((rc = dev_upload(&g->d_bk_ptr, h.bk_ptr, tot)) || (rc = dev_upload(&g->d_bk_grp, h.bk_grp, tot))) return rc;
         // byte opinions: 5-byte edge records (see k_step_f64_blocked) unless a chunk of 64 consecutive edges of a
         // workgroup spans more than 65535 positions (a few edges over very many peers) or positions need 33 bits
-        if (g->raw && g->val_bytes == 1 && vec_len <= 0xFFFFFFFFull && !getenv("ET_F64_UNPACKED")) {
+        // (a chunked exchange cuts a list into runs that do not start on a 64-edge boundary: 7-byte records there)
+        if (g->raw && g->val_bytes == 1 && vec_len <= 0xFFFFFFFFull && h.geo.n_chunks == 1 && !getenv("ET_F64_UNPACKED")) {
             const uint32_t B = h.geo.f64_blocks;
             std::vector<uint64_t> cptr((size_t)B + 1, 0);
             for (uint32_t b = 0; b < B; ++b) cptr[b + 1] = cptr[b] + (h.bk_ptr[b + 1] - h.bk_ptr[b] + 63) / 64;
@@ -1175,6 +1193,9 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
                 (void)hipFree(d_bv);
             }
         }
+        if (h.geo.n_chunks > 1) {
+            if ((rc = dev_upload(&g->d_bk_phase, h.bk_phase, tot)) || (rc = dev_alloc(&g->d_f64_acc, (size_t)h.geo.f64_blocks * h.geo.f64_rb, tot))) return rc;
+        }
         for (int i = 0; i < 2; ++i) {
             if ((rc = dev_alloc(&g->vx[i], vec_len, tot))) return rc;
             HIP_TRY(hipMemset(g->vx[i], 0, vec_len * sizeof(double)));
@@ -1198,6 +1219,10 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
         for (int i = 0; i < 2; ++i) {
             if ((rc = dev_alloc(&g->fx[i], vec_len * 2, tot))) return rc;
             HIP_TRY(hipMemset(g->fx[i], 0, vec_len * 32));
+        }
+        if (g->fr_blocked && h.geo.n_chunks > 1) {
+            const size_t words = h.geo.fr_compact ? 4 * (size_t)h.geo.fr_rb + h.geo.fr_rb / 2 : 8 * (size_t)h.geo.fr_rb;
+            if ((rc = dev_upload(&g->d_fb_phase, h.fb_phase, tot)) || (rc = dev_alloc(&g->d_fr_acc, (size_t)h.geo.fr_blocks * words, tot))) return rc;
         }
         if (g->fr_blocked) {
             if ((rc = dev_upload(&g->d_fb_ptr, h.fb_ptr, tot)) || (rc = dev_upload(&g->d_fb_grp, h.fb_grp, tot)) ||
@@ -1254,7 +1279,7 @@ static void launch_f64(const StepArgsF64B& a, unsigned blocks, size_t lds, hipSt
     if (a.alpha != 0.0) hipLaunchKernelGGL((k_step_f64_blocked<VT, true, PACKED>), dim3(blocks), dim3(1024), lds, st, a);
     else hipLaunchKernelGGL((k_step_f64_blocked<VT, false, PACKED>), dim3(blocks), dim3(1024), lds, st, a);
 }
-int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, uint32_t flags, hipStream_t st) {
+int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, uint32_t flags, hipStream_t st, int phase) {
     if (!(variants & ET_VARIANT_F64)) { set_error("graph was built without the f64 variant"); return ET_E_UNSUPPORTED; }
     if (x == y) { set_error("step needs distinct input and output vectors"); return ET_E_INVALID_ARG; }
     if (alpha != 0.0 && !pretrust) { set_error("alpha != 0 needs a pre-trust vector"); return ET_E_INVALID_ARG; }
@@ -1265,15 +1290,21 @@ int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double
     a.own = own64; a.scale = d_scale64;
     a.res_part = d_res_part + ring; a.sum_part = d_sum_part + ring;
     a.geo = geo; a.inv_nm1 = inv_nm1; a.alpha = alpha; a.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u;
+    a.phase_ptr = d_bk_phase; a.acc_g = d_f64_acc; a.n_phases = geo.n_chunks;
+    if (phase >= (int)geo.n_chunks) { set_error("no such phase"); return ET_E_OUT_OF_RANGE; }
     const size_t lds = (size_t)geo.f64_rb * sizeof(double);
-    if (!raw) launch_f64<double>(a, geo.f64_blocks, lds, st);
-    else if (packed) launch_f64<uint8_t, true>(a, geo.f64_blocks, lds, st);
-    else if (val_bytes == 1) launch_f64<uint8_t>(a, geo.f64_blocks, lds, st);
-    else launch_f64<uint32_t>(a, geo.f64_blocks, lds, st);
+    // phase < 0: the whole iteration, as n_chunks launches one after the other
+    for (uint32_t q = phase < 0 ? 0u : (uint32_t)phase; q < (phase < 0 ? geo.n_chunks : (uint32_t)phase + 1); ++q) {
+        a.phase = q;
+        if (!raw) launch_f64<double>(a, geo.f64_blocks, lds, st);
+        else if (packed) launch_f64<uint8_t, true>(a, geo.f64_blocks, lds, st);
+        else if (val_bytes == 1) launch_f64<uint8_t>(a, geo.f64_blocks, lds, st);
+        else launch_f64<uint32_t>(a, geo.f64_blocks, lds, st);
+    }
     HIP_TRY(hipGetLastError());
     return ET_OK;
 }
-int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t flags, hipStream_t st) {
+int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t flags, hipStream_t st, int phase) {
     if (!(variants & ET_VARIANT_FR)) { set_error("graph was built without the Fr variant"); return ET_E_UNSUPPORTED; }
     if (x == y) { set_error("step needs distinct input and output vectors"); return ET_E_INVALID_ARG; }
     if (fr_blocked) {
@@ -1282,13 +1313,18 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
         fb.ptr = d_fb_ptr; fb.grp = d_fb_grp; fb.col = d_fb_col; fb.row = d_fb_row; fb.val = d_fb_val; fb.x = x; fb.y = y;
         fb.own = own_fr; fb.scale288 = d_fb_scale; fb.sum_part = d_frsum_part + 2 * ringb; fb.chg_part = d_chg_part + ringb;
         fb.geo = geo; fb.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u; fb.inv_nm1_w = to_u256(inv_nm1_w);
-        { const char* dbg = getenv("ET_FR_DEBUG"); fb.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }
         fb.inv_nm1_w576 = to_u256((Fr::from_raw(inv_nm1_w) * Fr::one().pow2k(288)).to_raw());
-        if (geo.fr_compact) hipLaunchKernelGGL(k_step_fr_blocked<true>, dim3(geo.fr_blocks), dim3(1024), (size_t)geo.fr_rb * 36, st, fb);
-        else hipLaunchKernelGGL(k_step_fr_blocked<false>, dim3(geo.fr_blocks), dim3(1024), (size_t)geo.fr_rb * 64, st, fb);
+        fb.phase_ptr = d_fb_phase; fb.acc_g = d_fr_acc; fb.n_phases = geo.n_chunks;
+        if (phase >= (int)geo.n_chunks) { set_error("no such phase"); return ET_E_OUT_OF_RANGE; }
+        for (uint32_t q = phase < 0 ? 0u : (uint32_t)phase; q < (phase < 0 ? geo.n_chunks : (uint32_t)phase + 1); ++q) {
+            fb.phase = q;
+            if (geo.fr_compact) hipLaunchKernelGGL(k_step_fr_blocked<true>, dim3(geo.fr_blocks), dim3(1024), (size_t)geo.fr_rb * 36, st, fb);
+            else hipLaunchKernelGGL(k_step_fr_blocked<false>, dim3(geo.fr_blocks), dim3(1024), (size_t)geo.fr_rb * 64, st, fb);
+        }
         HIP_TRY(hipGetLastError());
         return ET_OK;
     }
+    if (phase > 0) { set_error("no such phase"); return ET_E_OUT_OF_RANGE; }   // n_chunks is 1 without the blocked sweep
     StepArgsFr a;
     a.work = d_work; a.slices = d_slices; a.col = d_col; a.wlo = d_wlo; a.whi = d_whi; a.val = d_val; a.x = x; a.y = y;
     a.own = own_fr; a.scale = d_scale_fr;

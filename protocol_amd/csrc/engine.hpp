@@ -64,6 +64,11 @@ struct DeviceGraph {
     uint16_t* d_fb_row = nullptr;
     uint8_t* d_fb_val = nullptr;
     uint4* d_fb_scale = nullptr;      // inv(sum) * 2^288 per position
+    // chunked exchange (geo.n_chunks > 1): runs of the workgroups' lists per piece, partial sums between an iteration's launches
+    uint64_t* d_bk_phase = nullptr;
+    uint64_t* d_fb_phase = nullptr;
+    double* d_f64_acc = nullptr;
+    unsigned long long* d_fr_acc = nullptr;
     uint4* d_wlo = nullptr;
     uint4* d_whi = nullptr;
     uint32_t* d_pos = nullptr;
@@ -88,8 +93,9 @@ struct DeviceGraph {
     // plain = true writes plain scores whatever the form (a vector that is read back, not iterated)
     int init_f64(double initial, double* x, hipStream_t st, bool plain = false);
     int init_fr(uint64_t lo, uint64_t hi, uint4* x, hipStream_t st, bool plain = false);
-    int step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, uint32_t flags, hipStream_t st);
-    int step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t flags, hipStream_t st);
+    // phase: which of the geo.n_chunks launches of the iteration to enqueue; -1 = all of them, one after the other
+    int step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, uint32_t flags, hipStream_t st, int phase = -1);
+    int step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t flags, hipStream_t st, int phase = -1);
     int unpermute_f64(const double* x, double* out, hipStream_t st);
     int unpermute_fr(const uint4* x, uint4* out, hipStream_t st);
     int stats_f64(uint32_t iteration, hipStream_t st, et_iter_stats* out);

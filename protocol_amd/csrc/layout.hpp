@@ -86,12 +86,22 @@ struct Geometry {
     // groups of dangling rows go to the first f64_dblocks workgroups only; workgroup b of those writes
     // partial-sum slot b of its segment, so nd_cap >= f64_dblocks
     uint32_t f64_dblocks;
-    // exact blocked sweep (byte opinions, 512K to 2M rows per share; 0 workgroups = not used): the same deal with a
+    // exact blocked sweep (byte opinions, 16K rows per share and more; 0 workgroups = not used): the same deal with a
     // row's unreduced sum in LDS.  fr_compact != 0: nine 32-bit limbs per row (36 bytes, carries propagated as the
-    // edges arrive), up to FR_RB_MAX_COMPACT rows per workgroup; else eight 64-bit column sums (64 bytes, no carries
-    // until the row is folded), up to FR_RB_MAX_WIDE rows.
+    // edges arrive), up to FR_RB_MAX_COMPACT rows per workgroup; else (a measurement knob) eight 64-bit column sums
+    // (64 bytes, no carries until the row is folded), up to FR_RB_MAX_WIDE rows.
     uint32_t fr_blocks, fr_rb, fr_dblocks, fr_compact;
+    // Chunked exchange (several GPUs): a segment travels in n_chunks pieces of chunk_rows rows (the last piece takes
+    // the rest and the partial-sum tail), and an iteration runs as n_chunks launches, launch q over the edges whose
+    // source lies in piece q of ANY segment; a workgroup's edge list is sorted by (piece, position).  1 = off.
+    uint32_t n_chunks, chunk_rows;
     ET_HD uint32_t seg_stride() const { return rows_cap + nd_cap; }
+    ET_HD uint32_t chunk_of_local(uint32_t local) const {
+        const uint32_t q = local / chunk_rows;
+        return q < n_chunks ? q : n_chunks - 1;
+    }
+    // piece q of a segment: entries [chunk_begin(q), chunk_begin(q + 1)) of its rows_cap + nd_cap
+    ET_HD uint32_t chunk_begin(uint32_t q) const { return q >= n_chunks ? seg_stride() : q * chunk_rows; }
     ET_HD uint32_t pos_of_col(uint32_t c) const { return (c >> COL_SEG_SHIFT) * seg_stride() + (c & COL_LOCAL_MASK); }
 };
 

@@ -13,10 +13,18 @@
 // ranks of one communicator on one device) or on request, every share PULLS the other shares' segments with
 // device-to-device copies ordered by events; on a fully connected xGMI node that puts one segment on each
 // link, which is also what the best all-gather does there.
+//
+// Chunked exchange (n_chunks = K > 1).  The exchange moves more bytes per iteration than the kernels take time for,
+// so a converge that runs kernel, exchange, kernel, ... leaves the GPUs idle most of the time.  With K pieces per
+// segment an iteration runs as K launches, launch q over the edges whose sources lie in piece q of any segment, and
+// the pieces travel on a second stream per share: launch q waits for piece q only, and piece q + 1 arrives while it
+// runs.  Pieces are pulled piece by piece (all segments' piece 0 first), over RCCL as an all-gather into a staging
+// buffer followed by a strided copy into place.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -91,6 +99,10 @@ struct et_sharded {
     std::vector<int> device;
     std::vector<DeviceGraph*> g;
     std::vector<hipStream_t> stream;
+    std::vector<hipStream_t> cstream;         // chunked exchange: the stream the pieces travel on
+    std::vector<hipEvent_t> ready;            // chunked exchange: [share * n_chunks + q] piece q of every segment is here
+    std::vector<void*> staging;               // chunked exchange over RCCL: world x (longest piece) per share
+    uint32_t n_chunks = 1;
     std::vector<hipEvent_t> done;             // share r's segment of the vector just written is complete
     std::vector<void*> vec[2];                // per share: two full-length vectors, sized for the widest variant built
     std::vector<double*> pretrust;            // per share, f64 with alpha != 0 only
@@ -110,6 +122,10 @@ struct et_sharded {
             for (int b = 0; b < 2; ++b) if (r < vec[b].size() && vec[b][r]) (void)hipFree(vec[b][r]);
             if (r < pretrust.size() && pretrust[r]) (void)hipFree(pretrust[r]);
             if (r < done.size() && done[r]) (void)hipEventDestroy(done[r]);
+            for (uint32_t q = 0; q < n_chunks; ++q)
+                if ((size_t)r * n_chunks + q < ready.size() && ready[(size_t)r * n_chunks + q]) (void)hipEventDestroy(ready[(size_t)r * n_chunks + q]);
+            if (r < staging.size() && staging[r]) (void)hipFree(staging[r]);
+            if (r < cstream.size() && cstream[r]) { (void)hipStreamSynchronize(cstream[r]); (void)hipStreamDestroy(cstream[r]); }
             if (r < stream.size() && stream[r]) (void)hipStreamDestroy(stream[r]);
             if (r < g.size()) delete g[r];
             if (r == 0 && out_dev) (void)hipFree(out_dev);
@@ -154,11 +170,64 @@ struct et_sharded {
     }
 };
 
+// Chunked exchange of buffer `b`, just written by every share (init, or the last launch of an iteration): the pieces
+// travel on the shares' second streams in order 0 .. K-1, and ready[share][q] fires when piece q of every segment has
+// reached `share`.  The next iteration's launch q waits for that event only.
+static int start_chunked_exchange(et_sharded* s, int b, size_t elem) {
+    const uint32_t W = s->world, K = s->n_chunks;
+    const Geometry& geo = s->g[0]->geo;
+    for (uint32_t r = 0; r < W; ++r) {
+        HIP_TRY_S(hipSetDevice(s->device[r]));
+        HIP_TRY_S(hipEventRecord(s->done[r], s->stream[r]));
+    }
+    for (uint32_t r = 0; r < W; ++r) {
+        HIP_TRY_S(hipSetDevice(s->device[r]));
+        for (uint32_t q = 0; q < W; ++q) HIP_TRY_S(hipStreamWaitEvent(s->cstream[r], s->done[q], 0));   // every producer, the share itself included
+    }
+    for (uint32_t q = 0; q < K; ++q) {
+        const size_t off = (size_t)geo.chunk_begin(q) * elem, len = (size_t)(geo.chunk_begin(q + 1) - geo.chunk_begin(q)) * elem;
+        const size_t seg_bytes = s->seg_stride * elem;
+        if (s->exchange == ET_EXCHANGE_RCCL) {
+            RCCL_TRY(rccl().GroupStart());
+            for (uint32_t r = 0; r < W; ++r) {
+                char* base = static_cast<char*>(s->vec[b][r]);
+                ncclResult_t rc = rccl().AllGather(base + r * seg_bytes + off, s->staging[r], len, ncclChar, s->comm[r], s->cstream[r]);
+                if (rc != ncclSuccess) {
+                    (void)rccl().GroupEnd();
+                    set_error(std::string("ncclAllGather: ") + rccl().GetErrorString(rc));
+                    return ET_E_RCCL;
+                }
+            }
+            RCCL_TRY(rccl().GroupEnd());
+            for (uint32_t r = 0; r < W; ++r) {          // staging [segment][piece] -> piece q of every segment of the vector
+                HIP_TRY_S(hipSetDevice(s->device[r]));
+                HIP_TRY_S(hipMemcpy2DAsync(static_cast<char*>(s->vec[b][r]) + off, seg_bytes, s->staging[r], len, len, W,
+                                           hipMemcpyDeviceToDevice, s->cstream[r]));
+            }
+        } else {
+            for (uint32_t dst = 0; dst < W; ++dst) {
+                HIP_TRY_S(hipSetDevice(s->device[dst]));
+                for (uint32_t k = 1; k < W; ++k) {
+                    const uint32_t src = (dst + k) % W;
+                    HIP_TRY_S(hipMemcpyAsync(static_cast<char*>(s->vec[b][dst]) + src * seg_bytes + off,
+                                             static_cast<char*>(s->vec[b][src]) + src * seg_bytes + off, len, hipMemcpyDeviceToDevice,
+                                             s->cstream[dst]));
+                }
+            }
+        }
+        for (uint32_t r = 0; r < W; ++r) {
+            HIP_TRY_S(hipSetDevice(s->device[r]));
+            HIP_TRY_S(hipEventRecord(s->ready[(size_t)r * K + q], s->cstream[r]));
+        }
+    }
+    return ET_OK;
+}
+
 extern "C" {
 
 int et_sharded_create(uint32_t n, const uint8_t* member, uint64_t n_edges, const uint32_t* from, const uint32_t* to,
                       const uint32_t* value_u32, const et_fr* value_fr, uint32_t n_devices, const int32_t* devices,
-                      uint32_t variants, uint32_t exchange, et_sharded** out) {
+                      uint32_t variants, uint32_t exchange, uint32_t n_chunks, et_sharded** out) {
     if (!out || n_devices == 0 || !devices) return ET_E_INVALID_ARG;
     if (n_devices > 8) { set_error("at most 8 shares"); return ET_E_UNSUPPORTED; }
     int ndev = 0;
@@ -190,6 +259,7 @@ int et_sharded_create(uint32_t n, const uint8_t* member, uint64_t n_edges, const
     if (n_edges == 0 && !value_u32 && !value_fr) in.val_u32 = &dummy32;
     BuildOpts bo;
     bo.n_seg = n_devices;
+    if (n_chunks > 1 && n_devices > 1) bo.n_chunks = n_chunks;
     PlanCommon pc;
     std::string err;
     int rc = plan_common(in, bo, pc, err);
@@ -204,6 +274,7 @@ int et_sharded_create(uint32_t n, const uint8_t* member, uint64_t n_edges, const
     }
     s->vec_len = s->g[0]->vec_len;
     s->seg_stride = s->g[0]->geo.seg_stride();
+    s->n_chunks = s->g[0]->geo.n_chunks;        // 1 where the graph does not take the blocked sweeps
     const size_t elem = (s->variants & ET_VARIANT_FR) ? 32 : 8;
     s->stream.assign(n_devices, nullptr);
     s->done.assign(n_devices, nullptr);
@@ -225,6 +296,20 @@ int et_sharded_create(uint32_t n, const uint8_t* member, uint64_t n_edges, const
                     (void)hipGetLastError();
                 }
             }
+    }
+    if (s->n_chunks > 1) {
+        const Geometry& geo = s->g[0]->geo;
+        uint32_t longest = 0;
+        for (uint32_t q = 0; q < s->n_chunks; ++q) longest = std::max(longest, geo.chunk_begin(q + 1) - geo.chunk_begin(q));
+        s->cstream.assign(n_devices, nullptr);
+        s->ready.assign((size_t)n_devices * s->n_chunks, nullptr);
+        s->staging.assign(n_devices, nullptr);
+        for (uint32_t r = 0; r < n_devices; ++r) {
+            HIP_TRY_S(hipSetDevice(devices[r]));
+            HIP_TRY_S(hipStreamCreateWithFlags(&s->cstream[r], hipStreamNonBlocking));
+            for (uint32_t q = 0; q < s->n_chunks; ++q) HIP_TRY_S(hipEventCreateWithFlags(&s->ready[(size_t)r * s->n_chunks + q], hipEventDisableTiming));
+            if (exchange == ET_EXCHANGE_RCCL) HIP_TRY_S(hipMalloc(&s->staging[r], (size_t)n_devices * longest * elem));
+        }
     }
     HIP_TRY_S(hipSetDevice(devices[0]));
     HIP_TRY_S(hipMalloc(&s->out_dev, (size_t)n * elem));
@@ -253,22 +338,28 @@ int et_sharded_converge_fr(et_sharded* s, uint32_t num_iterations, uint64_t init
         HIP_TRY_S(hipSetDevice(s->device[r]));
         if ((rc = s->g[r]->init_fr(initial_lo, initial_hi, (uint4*)s->vec[0][r], s->stream[r], num_iterations == 0))) return rc;
     }
-    if ((rc = s->exchange_segments(0, 32))) return rc;
+    const bool chunked = s->n_chunks > 1;
+    if ((rc = chunked ? start_chunked_exchange(s, 0, 32) : s->exchange_segments(0, 32))) return rc;
     for (uint32_t it = 0; it < num_iterations; ++it) {
         const int a = it & 1, b = (it + 1) & 1;
-        for (uint32_t r = 0; r < s->world; ++r) {
-            HIP_TRY_S(hipSetDevice(s->device[r]));
-            if ((rc = s->g[r]->step_fr((const uint4*)s->vec[a][r], (uint4*)s->vec[b][r], it,
-                                       it + 1 == num_iterations ? ET_STEP_FINAL : 0u, s->stream[r]))) return rc;
-        }
-        if ((rc = s->exchange_segments(b, 32))) return rc;
+        const uint32_t flags = it + 1 == num_iterations ? ET_STEP_FINAL : 0u;
+        for (uint32_t q = 0; q < s->n_chunks; ++q)
+            for (uint32_t r = 0; r < s->world; ++r) {
+                HIP_TRY_S(hipSetDevice(s->device[r]));
+                if (chunked) HIP_TRY_S(hipStreamWaitEvent(s->stream[r], s->ready[(size_t)r * s->n_chunks + q], 0));
+                if ((rc = s->g[r]->step_fr((const uint4*)s->vec[a][r], (uint4*)s->vec[b][r], it, flags, s->stream[r], chunked ? (int)q : -1))) return rc;
+            }
+        if ((rc = chunked ? start_chunked_exchange(s, b, 32) : s->exchange_segments(b, 32))) return rc;
     }
+    if (chunked)   // the result is read from the first share's vector: all of its pieces must be in
+        for (uint32_t q = 0; q < s->n_chunks; ++q) { HIP_TRY_S(hipSetDevice(s->device[0])); HIP_TRY_S(hipStreamWaitEvent(s->stream[0], s->ready[q], 0)); }
     HIP_TRY_S(hipSetDevice(s->device[0]));
     if ((rc = s->g[0]->unpermute_fr((const uint4*)s->vec[num_iterations & 1][0], (uint4*)s->out_dev, s->stream[0]))) return rc;
     HIP_TRY_S(hipMemcpyAsync(out, s->out_dev, (size_t)s->n * 32, hipMemcpyDeviceToHost, s->stream[0]));
     for (uint32_t r = 0; r < s->world; ++r) {
         HIP_TRY_S(hipSetDevice(s->device[r]));
         HIP_TRY_S(hipStreamSynchronize(s->stream[r]));
+        if (chunked) HIP_TRY_S(hipStreamSynchronize(s->cstream[r]));
     }
     // conservation (native.rs:331-334) over the shares' partial sums
     if (num_iterations > 0) {
@@ -308,23 +399,29 @@ int et_sharded_converge_f64(et_sharded* s, uint32_t num_iterations, double initi
     }
     if (alpha != 0.0 && pretrust)   // the host staging vector must outlive the uploads
         for (uint32_t r = 0; r < s->world; ++r) { HIP_TRY_S(hipSetDevice(s->device[r])); HIP_TRY_S(hipStreamSynchronize(s->stream[r])); }
-    if ((rc = s->exchange_segments(0, 8))) return rc;
+    const bool chunked = s->n_chunks > 1;
+    if ((rc = chunked ? start_chunked_exchange(s, 0, 8) : s->exchange_segments(0, 8))) return rc;
     for (uint32_t it = 0; it < num_iterations; ++it) {
         const int a = it & 1, b = (it + 1) & 1;
-        for (uint32_t r = 0; r < s->world; ++r) {
-            HIP_TRY_S(hipSetDevice(s->device[r]));
-            if ((rc = s->g[r]->step_f64((const double*)s->vec[a][r], (double*)s->vec[b][r], it, alpha,
-                                        alpha != 0.0 ? s->pretrust[r] : nullptr, it + 1 == num_iterations ? ET_STEP_FINAL : 0u,
-                                        s->stream[r]))) return rc;
-        }
-        if ((rc = s->exchange_segments(b, 8))) return rc;
+        const uint32_t flags = it + 1 == num_iterations ? ET_STEP_FINAL : 0u;
+        for (uint32_t q = 0; q < s->n_chunks; ++q)
+            for (uint32_t r = 0; r < s->world; ++r) {
+                HIP_TRY_S(hipSetDevice(s->device[r]));
+                if (chunked) HIP_TRY_S(hipStreamWaitEvent(s->stream[r], s->ready[(size_t)r * s->n_chunks + q], 0));
+                if ((rc = s->g[r]->step_f64((const double*)s->vec[a][r], (double*)s->vec[b][r], it, alpha,
+                                            alpha != 0.0 ? s->pretrust[r] : nullptr, flags, s->stream[r], chunked ? (int)q : -1))) return rc;
+            }
+        if ((rc = chunked ? start_chunked_exchange(s, b, 8) : s->exchange_segments(b, 8))) return rc;
     }
+    if (chunked)
+        for (uint32_t q = 0; q < s->n_chunks; ++q) { HIP_TRY_S(hipSetDevice(s->device[0])); HIP_TRY_S(hipStreamWaitEvent(s->stream[0], s->ready[q], 0)); }
     HIP_TRY_S(hipSetDevice(s->device[0]));
     if ((rc = s->g[0]->unpermute_f64((const double*)s->vec[num_iterations & 1][0], (double*)s->out_dev, s->stream[0]))) return rc;
     HIP_TRY_S(hipMemcpyAsync(out, s->out_dev, (size_t)s->n * sizeof(double), hipMemcpyDeviceToHost, s->stream[0]));
     for (uint32_t r = 0; r < s->world; ++r) {
         HIP_TRY_S(hipSetDevice(s->device[r]));
         HIP_TRY_S(hipStreamSynchronize(s->stream[r]));
+        if (chunked) HIP_TRY_S(hipStreamSynchronize(s->cstream[r]));
     }
     if (residual_l1) {
         *residual_l1 = 0.0;

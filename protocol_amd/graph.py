@@ -42,7 +42,7 @@ class Graph:
 
     def __init__(self, n, frm, to, value_u32=None, value_fr=None, member=None, n_seg=1, seg=0,
                  variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64, device=-1, long_row=0,
-                 target_work=0):
+                 target_work=0, n_chunks=1):
         frm = np.ascontiguousarray(frm, dtype=np.uint32)
         to = np.ascontiguousarray(to, dtype=np.uint32)
         if len(frm) != len(to):
@@ -55,7 +55,7 @@ class Graph:
             member = np.ascontiguousarray(member, dtype=np.uint8)
             if len(member) != n:
                 raise ValueError("member flags must have n entries")
-        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, variants, device)
+        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, variants, device, n_chunks)
         h = C.c_void_p()
         check(lib().et_graph_build(n, _ptr(member), len(frm), _ptr(frm), _ptr(to), _ptr(value_u32),
                                    _ptr(value_fr), C.byref(opts), C.byref(h)))
@@ -142,12 +142,19 @@ class Graph:
     def init_f64(self, x_ptr, initial=1000.0, stream=None, plain=False):
         check(lib().et_graph_init_f64_async(self._h, initial, x_ptr, 1 if plain else 0, stream))
 
-    def step_fr(self, x_ptr, y_ptr, iteration, stream=None, final=False):
-        """One iteration; `final=True` on the last step of a converge (its output holds plain scores)."""
-        check(lib().et_graph_step_fr_async(self._h, x_ptr, y_ptr, iteration, 1 if final else 0, stream))
+    def step_fr(self, x_ptr, y_ptr, iteration, stream=None, final=False, phase=None):
+        """One iteration; `final=True` on the last step of a converge (its output holds plain scores).
+        `phase`: one of the info.n_chunks launches of the iteration (graphs built with n_chunks > 1), None = all."""
+        if phase is None:
+            check(lib().et_graph_step_fr_async(self._h, x_ptr, y_ptr, iteration, 1 if final else 0, stream))
+        else:
+            check(lib().et_graph_step_fr_phase_async(self._h, x_ptr, y_ptr, iteration, 1 if final else 0, phase, stream))
 
-    def step_f64(self, x_ptr, y_ptr, iteration, alpha=0.0, pretrust_ptr=None, stream=None, final=False):
-        check(lib().et_graph_step_f64_async(self._h, x_ptr, y_ptr, iteration, alpha, pretrust_ptr, 1 if final else 0, stream))
+    def step_f64(self, x_ptr, y_ptr, iteration, alpha=0.0, pretrust_ptr=None, stream=None, final=False, phase=None):
+        if phase is None:
+            check(lib().et_graph_step_f64_async(self._h, x_ptr, y_ptr, iteration, alpha, pretrust_ptr, 1 if final else 0, stream))
+        else:
+            check(lib().et_graph_step_f64_phase_async(self._h, x_ptr, y_ptr, iteration, alpha, pretrust_ptr, 1 if final else 0, phase, stream))
 
     def unpermute_fr(self, x_ptr, out_ptr, stream=None):
         check(lib().et_graph_unpermute_fr_async(self._h, x_ptr, out_ptr, stream))
@@ -161,7 +168,7 @@ class MultiGpuGraph:
     `devices` lists one HIP ordinal per share; the same ordinal twice rehearses the layout on fewer GPUs."""
 
     def __init__(self, n, frm, to, value_u32=None, value_fr=None, member=None, devices=(0,),
-                 variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64, exchange=_ffi.ET_EXCHANGE_AUTO):
+                 variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64, exchange=_ffi.ET_EXCHANGE_AUTO, n_chunks=1):
         frm = np.ascontiguousarray(frm, dtype=np.uint32)
         to = np.ascontiguousarray(to, dtype=np.uint32)
         if len(frm) != len(to):
@@ -175,7 +182,7 @@ class MultiGpuGraph:
         devs = np.ascontiguousarray(devices, dtype=np.int32)
         h = C.c_void_p()
         check(lib().et_sharded_create(n, _ptr(member), len(frm), _ptr(frm), _ptr(to), _ptr(value_u32), _ptr(value_fr),
-                                      len(devs), _ptr(devs), variants, exchange, C.byref(h)))
+                                      len(devs), _ptr(devs), variants, exchange, n_chunks, C.byref(h)))
         self._h = h
         self.n = n
         self.world = len(devs)
@@ -225,7 +232,7 @@ class Plan:
             value_fr = np.ascontiguousarray(value_fr, dtype=np.uint8)
         if member is not None:
             member = np.ascontiguousarray(member, dtype=np.uint8)
-        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, 0, -1)
+        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, 0, -1, 1)
         h = C.c_void_p()
         check(lib().et_plan_build(n, _ptr(member), len(frm), _ptr(frm), _ptr(to), _ptr(value_u32),
                                   _ptr(value_fr), C.byref(opts), C.byref(h)))

@@ -22,7 +22,7 @@ from .graph import Graph, R_MODULUS
 
 class ShardedGraph:
     def __init__(self, n, frm, to, value_u32=None, value_fr=None, member=None, group=None,
-                 device=None, variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64, always_exchange=False, **build_kw):
+                 device=None, variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64, always_exchange=False, n_chunks=1, **build_kw):
         # always_exchange: take the stepping + all-gather path even with a single rank (the collective is then a
         # copy of the vector onto itself): the way to run the RCCL call of this driver on a one-GPU box
         self.always_exchange = always_exchange
@@ -32,8 +32,13 @@ class ShardedGraph:
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.graph = Graph(n, frm, to, value_u32=value_u32, value_fr=value_fr, member=member,
                            n_seg=self.world, seg=self.rank, variants=variants,
-                           device=self.device.index if self.device.index is not None else -1, **build_kw)
+                           device=self.device.index if self.device.index is not None else -1,
+                           n_chunks=n_chunks if (self.world > 1 or always_exchange) else 1, **build_kw)
         info = self.graph.info
+        # chunked exchange: a segment travels in n_chunks pieces while the iteration's n_chunks launches run, launch q
+        # waiting for piece q only (1 where the graph does not take the blocked sweeps)
+        self.n_chunks = int(info.n_chunks)
+        self.chunk_rows = int(info.chunk_rows)
         self.n = n
         self.vec_len = int(info.vec_len)
         self.seg_stride = int(info.rows_cap + info.nd_cap)
@@ -72,6 +77,83 @@ class ShardedGraph:
                 if r != self.rank:
                     t[r * self.seg_stride:(r + 1) * self.seg_stride].copy_(p)
 
+    # ---- chunked exchange ------------------------------------------------------------------------
+    def _pieces(self):
+        k = self.n_chunks
+        return [(q * self.chunk_rows, (self.chunk_rows if q + 1 < k else self.seg_stride - q * self.chunk_rows)) for q in range(k)]
+
+    def _start_exchange(self, t, kind):
+        """Starts the exchange of every piece of the vector `t` (this rank's segment just written); returns what
+        _finish_piece needs.  With RCCL every piece is an asynchronous all-gather into a staging buffer: the
+        collectives run in order on the communicator's stream while the caller's stream goes on launching."""
+        pend = []
+        nccl = dist.get_backend(self.group) == "nccl"
+        for q, (lo, ln) in enumerate(self._pieces()):
+            mine = self._segment(t)[lo:lo + ln]
+            if nccl:
+                key = ("stage", kind, q)
+                if key not in self._vec:
+                    self._vec[key] = torch.empty((self.world * ln,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
+                stage = self._vec[key]
+                work = dist.all_gather_into_tensor(stage, mine, group=self.group, async_op=True)
+                pend.append((work, stage, lo, ln))
+            else:  # gloo (tests): through host memory, synchronously
+                host = mine.cpu().contiguous()
+                parts = [torch.empty_like(host) for _ in range(self.world)]
+                dist.all_gather(parts, host, group=self.group)
+                pend.append((None, parts, lo, ln))
+        return pend
+
+    def _finish_piece(self, t, pend, q):
+        """Makes piece q of every segment of `t` current on the caller's stream."""
+        work, got, lo, ln = pend[q]
+        if work is not None:
+            work.wait()                       # the current stream waits for the collective; the host does not
+            full = t.view((self.world, self.seg_stride) + tuple(t.shape[1:]))
+            full[:, lo:lo + ln].copy_(got.view((self.world, ln) + tuple(t.shape[1:])))
+        else:
+            for r, p in enumerate(got):
+                if r != self.rank:
+                    t[r * self.seg_stride + lo:r * self.seg_stride + lo + ln].copy_(p)
+
+    def _run_chunked(self, kind, num_iterations, initial, alpha, record):
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        g = self.graph
+        x, y, out = self._buffers(kind)
+        pre = None
+        if kind == "f64":
+            if alpha != 0.0:
+                if "pre" not in self._vec:
+                    self._vec["pre"] = torch.zeros_like(x)
+                g.init_f64(self._vec["pre"].data_ptr(), initial, st, plain=True)
+                pre = self._vec["pre"].data_ptr()
+            g.init_f64(x.data_ptr(), initial, st, plain=num_iterations == 0)
+        else:
+            g.init_fr(x.data_ptr(), initial, st, plain=num_iterations == 0)
+        pend = self._start_exchange(x, kind)
+        bufs = (x, y)
+        for it in range(num_iterations):
+            a, b = bufs[it & 1], bufs[(it + 1) & 1]
+            final = it + 1 == num_iterations
+            for q in range(self.n_chunks):
+                self._finish_piece(a, pend, q)
+                if record:
+                    g.record_begin(st)
+                if kind == "f64":
+                    g.step_f64(a.data_ptr(), b.data_ptr(), it, alpha, pre, st, final=final, phase=q)
+                else:
+                    g.step_fr(a.data_ptr(), b.data_ptr(), it, st, final=final, phase=q)
+                if record:
+                    g.record_end(st)
+            pend = self._start_exchange(b, kind)
+        last = bufs[num_iterations & 1]
+        for q in range(self.n_chunks):
+            self._finish_piece(last, pend, q)
+        if kind == "f64":
+            g.unpermute_f64(last.data_ptr(), out.data_ptr(), st)
+        else:
+            g.unpermute_fr(last.data_ptr(), out.data_ptr(), st)
+
     # ---- converge --------------------------------------------------------------------------------
     def run_f64(self, num_iterations=20, initial=1000.0, alpha=0.0, record=False):
         """Enqueues a whole converge; the slot-order result stays on the device (result_f64)."""
@@ -80,6 +162,8 @@ class ShardedGraph:
         if self.world == 1 and not self.always_exchange:  # no exchange step: the library's own back-to-back loop
             g.run_f64(num_iterations, initial, alpha, st, record)
             return
+        if self.n_chunks > 1:
+            return self._run_chunked("f64", num_iterations, initial, alpha, record)
         x, y, out = self._buffers("f64")
         pre = None
         if alpha != 0.0:  # default pre-trust: the initial scores (only this share's segment is read)
@@ -106,6 +190,8 @@ class ShardedGraph:
         if self.world == 1 and not self.always_exchange:
             g.run_fr(num_iterations, initial, st, record)
             return
+        if self.n_chunks > 1:
+            return self._run_chunked("fr", num_iterations, initial, 0.0, record)
         x, y, out = self._buffers("fr")
         g.init_fr(x.data_ptr(), initial, st, plain=num_iterations == 0)
         self._all_gather(x)

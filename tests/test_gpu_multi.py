@@ -79,3 +79,72 @@ def test_rccl_exchange_with_the_one_rank_a_single_gpu_allows():
     with pytest.raises(pa.EigenTrustError) as ei:
         pa.MultiGpuGraph(n, frm, to, value_u32=val, member=member, devices=[0, 99])
     assert ei.value.code == _ffi.ET_E_OUT_OF_RANGE
+
+
+@pytest.mark.parametrize("world,n,chunks", [(2, 60000, 2), (4, 100000, 4), (8, 200000, 3), (3, 70000, 8)])
+def test_chunked_exchange_matches_oracle(world, n, chunks):
+    """Segments exchanged in pieces on a second stream per share while the iteration's launches run, launch q waiting
+    for piece q only: the same scores as one exchange per iteration, whatever the number of pieces."""
+    frm, to, val, member = _graph(n, 21 + world)
+    iters = 12
+    rc, exp, nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000,
+                                                  n_threads=c_oracle.max_threads())
+    assert rc == 0
+    rc, _e, eld, eres, _n, _s = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000.0,
+                                                             n_threads=c_oracle.max_threads(), want_ld=True)
+    assert rc == 0
+    mg = pa.MultiGpuGraph(n, frm, to, value_u32=val, member=member, devices=[0] * world, n_chunks=chunks)
+    info = mg.info(0)
+    assert int(info.n_chunks) == chunks and int(info.exact_sweep_blocks) != 0
+    assert np.array_equal(mg.converge_fr(iters, 1000), exp)
+    o64, res = mg.converge_f64(iters, 1000.0)
+    assert _rel_l1(o64, eld) <= 1e-9
+    assert abs(res - eres) <= 1e-6 * max(1.0, abs(eres))
+    assert np.array_equal(mg.converge_fr(iters, 1000), exp)            # again on the same object
+    assert np.array_equal(mg.converge_fr(1, 1000),
+                          c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=1, initial=1000)[1])
+    assert pa.fr_ints_from_bytes(mg.converge_fr(0, 1000)) == [1000 if m else 0 for m in member]
+
+
+def test_chunks_fall_back_where_the_sweeps_do_not_apply():
+    # fewer than 16K rows per share: the exact variant runs row per lane there and the exchange stays whole
+    n = 20000
+    frm, to, val, member = _graph(n, 3)
+    mg = pa.MultiGpuGraph(n, frm, to, value_u32=val, member=member, devices=[0, 0], n_chunks=4)
+    assert int(mg.info(0).n_chunks) == 1
+    rc, exp, _nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=5, initial=1000)
+    assert rc == 0 and np.array_equal(mg.converge_fr(5, 1000), exp)
+
+
+def test_one_graph_stepped_in_phases():
+    """et_graph_step_* on a graph built for a chunked exchange runs an iteration as its launches in a row; stepping
+    the phases one by one gives the same vector."""
+    import torch
+    n = 70000
+    frm, to, val, member = _graph(n, 8)
+    iters = 4
+    rc, exp, _nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000)
+    assert rc == 0
+    rc, _e, eld, _r, _n, _s = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000.0, want_ld=True)
+    assert rc == 0
+    g = pa.Graph(n, frm, to, value_u32=val, member=member, n_chunks=3)
+    assert int(g.info.n_chunks) == 3
+    assert np.array_equal(g.converge_fr(iters, 1000), exp)
+    o64, _ = g.converge_f64(iters, 1000.0)
+    assert _rel_l1(o64, eld) <= 1e-9
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    vec_len = int(g.info.vec_len)
+    x = torch.full((vec_len, 4), -1, dtype=torch.int64, device=dev)
+    y = torch.full((vec_len, 4), -1, dtype=torch.int64, device=dev)
+    g.init_fr(x.data_ptr(), 1000, st)
+    for it in range(iters):
+        for q in range(3):
+            g.step_fr(x.data_ptr(), y.data_ptr(), it, st, final=it + 1 == iters, phase=q)
+        x, y = y, x
+    out = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+    g.unpermute_fr(x.data_ptr(), out.data_ptr(), st)
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(out.cpu().numpy().view(np.uint8).reshape(n, 32), exp)
+    with pytest.raises(pa.EigenTrustError):
+        g.step_fr(x.data_ptr(), y.data_ptr(), 0, st, phase=3)

@@ -26,8 +26,10 @@ def _worker(rank, world, port, case, ret):
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    n, member, frm, to, val, iters = case
-    sg = ShardedGraph(n, frm, to, value_u32=val, member=member, device=torch.device("cuda", 0))
+    n, member, frm, to, val, iters = case[:6]
+    chunks = case[6] if len(case) > 6 else 1
+    sg = ShardedGraph(n, frm, to, value_u32=val, member=member, device=torch.device("cuda", 0), n_chunks=chunks)
+    assert sg.n_chunks == chunks
     fr = sg.converge_fr(iters, 1000)          # raises on a conservation failure
     f64 = sg.converge_f64(iters, 1000.0)
     damped = sg.converge_f64(iters, 1000.0, alpha=0.15)     # default pre-trust: the initial scores
@@ -42,8 +44,8 @@ def _worker(rank, world, port, case, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_converge_matches_oracle(world):
+@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 1), (2, 3)])
+def test_sharded_converge_matches_oracle(world, chunks):
     import c_oracle
     import protocol_amd as pa
     n = 50000
@@ -58,8 +60,8 @@ def test_sharded_converge_matches_oracle(world):
     assert rc == 0
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29500 + (os.getpid() + world) % 2000
-    mp.spawn(_worker, args=(world, port, (n, member, frm, to, val, iters), ret), nprocs=world, join=True)
+    port = 29500 + (os.getpid() + world + 10 * chunks) % 2000
+    mp.spawn(_worker, args=(world, port, (n, member, frm, to, val, iters, chunks), ret), nprocs=world, join=True)
     assert ret["nnz"] == nnz
     assert ret["fr"] == exp.tobytes()
     got = np.array(ret["f64"], dtype=np.longdouble)
@@ -137,15 +139,18 @@ def _nccl_worker(rank, world, port, case, ret):
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    n, member, frm, to, val, iters = case
-    sg = ShardedGraph(n, frm, to, value_u32=val, member=member, device=dev, always_exchange=True)
+    n, member, frm, to, val, iters = case[:6]
+    chunks = case[6] if len(case) > 6 else 1
+    sg = ShardedGraph(n, frm, to, value_u32=val, member=member, device=dev, always_exchange=True, n_chunks=chunks)
+    assert sg.n_chunks == chunks
     ret["fr"] = sg.converge_fr(iters, 1000).tobytes()      # conservation checked through the 32-byte tensor gather
     ret["f64"] = sg.converge_f64(iters, 1000.0).tolist()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_rccl_backend_with_the_one_rank_a_single_gpu_allows():
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_rccl_backend_with_the_one_rank_a_single_gpu_allows(chunks):
     """The driver's RCCL calls themselves (in-place all_gather_into_tensor of the segments, the 32-byte gather of the
     conservation check) with backend nccl: one rank is all a single GPU allows, so the collective copies the vector
     onto itself, but it is the same call, on the same tensors, that N ranks make."""
@@ -164,7 +169,7 @@ def test_rccl_backend_with_the_one_rank_a_single_gpu_allows():
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 29500 + (os.getpid() + 7) % 2000
-    mp.spawn(_nccl_worker, args=(1, port, (n, member, frm, to, val, iters), ret), nprocs=1, join=True)
+    mp.spawn(_nccl_worker, args=(1, port, (n, member, frm, to, val, iters, chunks), ret), nprocs=1, join=True)
     assert ret["fr"] == exp.tobytes()
     got = np.array(ret["f64"], dtype=np.longdouble)
     assert float(np.abs(got - eld).sum() / np.abs(eld).sum()) <= 1e-9

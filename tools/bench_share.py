@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--workload", default="c4", choices=["c3", "c4"])
     ap.add_argument("--ranks", type=int, nargs="+", default=[8])
     ap.add_argument("--launches", type=int, default=20)
+    ap.add_argument("--chunks", type=int, default=1, help="pieces of a chunked exchange: an iteration = that many launches")
     args = ap.parse_args()
 
     import torch
@@ -35,11 +36,12 @@ def main():
     st = torch.cuda.current_stream(dev).cuda_stream
     for world in args.ranks:
         t0 = time.time()
-        g = Graph(n, frm, to, value_u32=val, n_seg=world, seg=0, variants=3, device=0)
+        g = Graph(n, frm, to, value_u32=val, n_seg=world, seg=0, variants=3, device=0, n_chunks=args.chunks)
         t_build = time.time() - t0
         info = g.info
         vec_len = int(info.vec_len)
-        out = {"ranks": world, "rows": int(info.n_valid) // world, "edges": int(info.nnz_local), "build_s": round(t_build, 2)}
+        out = {"ranks": world, "rows": int(info.n_valid) // world, "edges": int(info.nnz_local), "build_s": round(t_build, 2),
+               "chunks": int(info.n_chunks)}
         for kind_, shape, dt in (("f64", (vec_len,), torch.float64), ("fr", (vec_len, 4), torch.int64)):
             x = torch.zeros(shape, dtype=dt, device=dev)
             y = torch.zeros(shape, dtype=dt, device=dev)
