@@ -229,11 +229,18 @@ def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu):
 
     kind, n, target_edges, desc = WORKLOADS[wl]
     t0 = time.time()
-    frm, to, val = pa.synth_graph(kind, n, target_edges, seed=args.seed, value_max=255)
+    if world == 1:
+        frm, to, val = pa.synth_graph(kind, n, target_edges, seed=args.seed, value_max=255)
+    else:
+        # every rank ingests the attestations of its own range of attesters only; the ranks agree on the layout and
+        # send each edge to the rank that owns its destination row (no rank holds the whole list)
+        frm, to, val = pa.synth_graph_range(kind, n, target_edges, n * rank // world, n * (rank + 1) // world,
+                                            seed=args.seed, value_max=255)
     t_gen = time.time() - t0
     variants = {"both": 3, "fr": 1, "f64": 2}[args.variant]
     t0 = time.time()
-    sg = ShardedGraph(n, frm, to, value_u32=val, device=device, variants=variants, n_chunks=args.chunks)
+    sg = ShardedGraph(n, frm, to, value_u32=val, device=device, variants=variants, n_chunks=args.chunks,
+                      local_attestations=world > 1)
     t_build = time.time() - t0
     info = sg.graph.info
     nnz = int(info.nnz)

@@ -65,6 +65,10 @@ pub struct et_batch {
 pub struct et_sharded {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct et_dplan {
+    _private: [u8; 0],
+}
 pub const ET_EXCHANGE_AUTO: u32 = 0;
 pub const ET_EXCHANGE_RCCL: u32 = 1;
 pub const ET_EXCHANGE_COPY: u32 = 2;
@@ -269,8 +273,27 @@ extern "C" {
     pub fn et_sharded_converge_f64(s: *mut et_sharded, num_iterations: u32, initial: f64, alpha: f64,
                                    pretrust: *const f64, out: *mut f64, residual_l1: *mut f64) -> c_int;
 
+    // ---- one share from the attestations of this process's own attesters ----
+    pub fn et_dplan_create(n: u32, member: *const u8, n_edges: u64, from: *const u32, to: *const u32,
+                           value_u32: *const u32, out: *mut *mut et_dplan) -> c_int;
+    pub fn et_dplan_local_stats(p: *const et_dplan, row_sum: *mut u64, in_degree: *mut u32, out_degree: *mut u32,
+                                value_max: *mut u32) -> c_int;
+    pub fn et_dplan_set_global_stats(p: *mut et_dplan, row_sum: *const u64, in_degree: *const u32,
+                                     out_degree: *const u32, value_max: u32, opts: *const et_build_opts) -> c_int;
+    pub fn et_dplan_outgoing(p: *const et_dplan, share: u32, count: *mut u64, src: *mut *const u32,
+                             row: *mut *const u32, value: *mut *const u32) -> c_int;
+    pub fn et_dplan_add_incoming(p: *mut et_dplan, count: u64, src: *const u32, row: *const u32,
+                                 value: *const u32) -> c_int;
+    pub fn et_dplan_info_get(p: *const et_dplan, info: *mut et_graph_info) -> c_int;
+    pub fn et_dplan_finish(p: *mut et_dplan, out: *mut *mut et_graph) -> c_int;
+    pub fn et_dplan_finish_host(p: *mut et_dplan, out: *mut *mut et_plan) -> c_int;
+    pub fn et_dplan_free(p: *mut et_dplan);
+
     pub fn et_synth_graph(kind: u32, n: u32, target_edges: u64, seed: u64, value_max: u32, n_edges: *mut u64,
                           from: *mut u32, to: *mut u32, value: *mut u32) -> c_int;
+    pub fn et_synth_graph_range(kind: u32, n: u32, target_edges: u64, seed: u64, value_max: u32, attester_begin: u32,
+                                attester_end: u32, n_edges: *mut u64, from: *mut u32, to: *mut u32,
+                                value: *mut u32) -> c_int;
 
     // ---- around converge: threshold, score records, files, public inputs ----
     pub fn et_ratio_decompose(num_le: *const u8, num_len: usize, den_le: *const u8, den_len: usize, num_limbs: u32,

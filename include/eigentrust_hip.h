@@ -304,6 +304,49 @@ int et_sharded_converge_f64(et_sharded *s, uint32_t num_iterations, double initi
                             const double *pretrust, double *out, double *residual_l1);
 
 /* ------------------------------------------------------------------------------------------
+ * One share of a row-sharded graph, laid out by a process that holds only the attestations of ITS OWN
+ * attesters (one process per GPU, each ingesting a disjoint set of attesters): no process ever holds the
+ * whole attestation list.  The reference builds its matrix from the whole list in one process
+ * (eigentrust/src/lib.rs:398-440); the filter, the last-write-wins rule and the row sums applied here are
+ * the same ones (native.rs:234-283, :305-314), per attester, which is why EVERY attestation of an attester
+ * must be given to the same process, in its original order.  Integer opinions only.
+ *   1. et_dplan_create        : this process's attestations; filter, row sums, degrees.
+ *   2. et_dplan_local_stats   : per-peer figures (n entries each).  The caller sums row_sum, in_degree and
+ *                               out_degree over the processes and takes the maximum of value_max (one
+ *                               all-reduce each), then
+ *      et_dplan_set_global_stats: the summed figures and the build options (n_seg = number of shares, seg =
+ *                               this process's share; variants, device, n_chunks as for et_graph_build).
+ *                               Every process derives the same order, geometry and positions.
+ *                               ET_E_INVALID_ARG when an attester's attestations reached two processes.
+ *   3. et_dplan_outgoing      : the surviving local edges whose destination row share `share` owns, as three
+ *                               parallel arrays (source position code, destination local row, opinion); the
+ *                               caller delivers them (one all-to-all), own share included, and hands what it
+ *                               received to et_dplan_add_incoming, in any order, in any number of calls.
+ *   4. et_dplan_finish        : lays out the share from the records received and uploads it; the graph steps
+ *                               and exchanges like one built by et_graph_build with the same n_seg / seg, and
+ *                               its results are the same bits.
+ * The pointers et_dplan_outgoing returns stay valid until et_dplan_finish or et_dplan_free.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct et_dplan et_dplan;
+int et_dplan_create(uint32_t n, const uint8_t *member, uint64_t n_edges, const uint32_t *from,
+                    const uint32_t *to, const uint32_t *value_u32, et_dplan **out);
+int et_dplan_local_stats(const et_dplan *p, uint64_t *row_sum, uint32_t *in_degree,
+                         uint32_t *out_degree, uint32_t *value_max);
+int et_dplan_set_global_stats(et_dplan *p, const uint64_t *row_sum, const uint32_t *in_degree,
+                              const uint32_t *out_degree, uint32_t value_max,
+                              const et_build_opts *opts);
+int et_dplan_outgoing(const et_dplan *p, uint32_t share, uint64_t *count, const uint32_t **src,
+                      const uint32_t **row, const uint32_t **value);
+int et_dplan_add_incoming(et_dplan *p, uint64_t count, const uint32_t *src, const uint32_t *row,
+                          const uint32_t *value);
+/* Geometry of the share (n_valid, n_dangling, nnz, rows_cap, nd_cap, vec_len, n_chunks ...): valid after step 2. */
+int et_dplan_info_get(const et_dplan *p, et_graph_info *info);
+int et_dplan_finish(et_dplan *p, et_graph **out);
+/* Step 4 without a GPU: the share's host-side plan (et_plan_info_get, et_plan_arrays_get, et_graph_from_plan). */
+int et_dplan_finish_host(et_dplan *p, et_plan **out);
+void et_dplan_free(et_dplan *p);
+
+/* ------------------------------------------------------------------------------------------
  * Batches of small independent sets (ZK witness generation): n_sets sets of n <= 1024 slots.
  * One workgroup per set runs the whole converge in a single launch; sets never communicate, so a
  * batch is split over GPUs by creating one sub-batch per GPU.  Sets whose opinions fit a byte (the
@@ -353,6 +396,11 @@ int et_batch_converge_fr_noalloc(uint32_t n_sets, uint32_t n, const uint8_t *mem
 int et_synth_graph(uint32_t kind, uint32_t n, uint64_t target_edges, uint64_t seed,
                    uint32_t value_max, uint64_t *n_edges, uint32_t *from, uint32_t *to,
                    uint32_t *value);
+/* The same list restricted to the attesters [attester_begin, attester_end): what one of several ingesting
+ * processes generates.  The concatenation over a partition of [0, n) is et_synth_graph's list. */
+int et_synth_graph_range(uint32_t kind, uint32_t n, uint64_t target_edges, uint64_t seed,
+                         uint32_t value_max, uint32_t attester_begin, uint32_t attester_end,
+                         uint64_t *n_edges, uint32_t *from, uint32_t *to, uint32_t *value);
 
 /* ------------------------------------------------------------------------------------------
  * Around the converge path (host side): threshold check, score packaging, the client's CSV

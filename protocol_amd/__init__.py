@@ -6,7 +6,8 @@ Everything computes on the GPU through protocol_amd/lib/libeigentrust_hip.so; th
 from ._ffi import EigenTrustError, LIB_PATH, lib  # noqa: F401
 from .eigentrust_set import (EigenTrustSet, INITIAL_SCORE, MIN_PEER_COUNT, NUM_ITERATIONS,  # noqa: F401
                              NUM_NEIGHBOURS)
-from .graph import Batch, Graph, MultiGpuGraph, Plan, R_MODULUS, fr_bytes_from_ints, fr_ints_from_bytes, synth_graph  # noqa: F401
+from .graph import (Batch, DistributedPlan, Graph, MultiGpuGraph, Plan, R_MODULUS, fr_bytes_from_ints,  # noqa: F401
+                    fr_ints_from_bytes, synth_graph, synth_graph_range)
 from .scores import (ETPublicInputs, Score, SignedAttestationRaw, Threshold, attestation_hash, big_to_fe_rat,  # noqa: F401
                      calculate_scores, et_circuit_setup, keccak256, opinion_validate, pack_score, poseidon5_permute,
                      poseidon5_sponge, public_key_of_secret, read_attestations_csv, recover_attesters,

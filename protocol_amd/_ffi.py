@@ -156,6 +156,16 @@ PROTOTYPES = {
     "et_batch_converge_fr": (i32, [u32, u32, vp, vp, u32, u64, u64, vp, vp]),
     "et_batch_converge_fr_noalloc": (i32, [u32, u32, vp, vp, u32, u64, u64, vp, vp]),
     "et_synth_graph": (i32, [u32, u32, u64, u64, u32, P(u64), vp, vp, vp]),
+    "et_synth_graph_range": (i32, [u32, u32, u64, u64, u32, u32, u32, P(u64), vp, vp, vp]),
+    "et_dplan_create": (i32, [u32, vp, u64, vp, vp, vp, P(vp)]),
+    "et_dplan_local_stats": (i32, [vp, vp, vp, vp, P(u32)]),
+    "et_dplan_set_global_stats": (i32, [vp, vp, vp, vp, u32, P(EtBuildOpts)]),
+    "et_dplan_outgoing": (i32, [vp, u32, P(u64), P(vp), P(vp), P(vp)]),
+    "et_dplan_add_incoming": (i32, [vp, u64, vp, vp, vp]),
+    "et_dplan_info_get": (i32, [vp, P(EtGraphInfo)]),
+    "et_dplan_finish": (i32, [vp, P(vp)]),
+    "et_dplan_finish_host": (i32, [vp, P(vp)]),
+    "et_dplan_free": (None, [vp]),
     "et_dev_fr_mul": (i32, [u32, vp, vp, vp]),
     "et_ratio_decompose": (i32, [vp, C.c_size_t, vp, C.c_size_t, u32, u32, vp, vp]),
     "et_threshold_check": (i32, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, u32, u32, u32, u64, u64, P(C.c_int)]),

@@ -24,15 +24,154 @@ struct Pos {  // global sorted row -> (segment, local row, position)
 
 }  // namespace
 
-int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& pc, std::string& err) {
+// Step 5 of the plan: the global row order, the geometry every share derives alike, and each peer's position.
+int layout_common(uint32_t n, const uint8_t* member, bool values_are_u32, const std::vector<uint8_t>& dangling, const PeerStats& st,
+                  const BuildOpts& opt, HostGraph& g, std::vector<uint32_t>& order, std::string& err) {
+    auto is_member = [&](uint32_t i) { return member ? member[i] != 0 : true; };
+    const uint32_t n_valid = g.n_valid;
+    uint32_t n_dangling = 0;
+    for (uint32_t i = 0; i < n; ++i) n_dangling += is_member(i) && dangling[i];
+    // ---- 5. global row order ------------------------------------------------------------------
+    // Active peers: the opt.hot_prefix most-gathered (highest out-degree), then the rest; inside each
+    // group by in-degree (descending) so that the 64 rows of a slice have similar lengths.  Dangling
+    // peers follow.
+    const uint32_t n_active = n_valid - n_dangling;
+    order.clear();
+    order.reserve(n_valid);
+    for (uint32_t i = 0; i < n; ++i) if (is_member(i) && !dangling[i]) order.push_back(i);
+    for (uint32_t i = 0; i < n; ++i) if (is_member(i) && dangling[i]) order.push_back(i);
+    auto by_deg = [&](uint32_t a, uint32_t b) {
+        if (st.in_deg[a] != st.in_deg[b]) return st.in_deg[a] > st.in_deg[b];
+        if (st.out_deg[a] != st.out_deg[b]) return st.out_deg[a] > st.out_deg[b];
+        return a < b;
+    };
+    auto by_out = [&](uint32_t a, uint32_t b) {
+        if (st.out_deg[a] != st.out_deg[b]) return st.out_deg[a] > st.out_deg[b];
+        return a < b;
+    };
+    {
+        const uint32_t h1 = std::min<uint32_t>(n_active, opt.hot_prefix);
+        auto b = order.begin();
+        if (h1 < n_active) std::nth_element(b, b + h1, b + n_active, by_out);
+        std::sort(b, b + h1, by_deg);
+        std::sort(b + h1, b + n_active, by_deg);
+    }
+    std::sort(order.begin() + n_active, order.end(), by_deg);
+
+    const uint32_t G = opt.n_seg;
+    Geometry geo{};
+    geo.n_seg = G;
+    geo.seg = opt.seg;
+    geo.n_active = n_active;
+    geo.n_active_pad = round_up(n_active, 64 * G);
+    geo.n_dangling = n_dangling;
+    geo.n_dangling_pad = round_up(n_dangling, 64 * G);
+    geo.rows_cap = (geo.n_active_pad + geo.n_dangling_pad) / G;
+    // one partial-sum slot per wavefront that owns dangling rows; the count depends only on global
+    // quantities so that every segment derives the same geometry
+    const uint32_t target_work = opt.target_work ? opt.target_work : 16384;
+    {
+        uint64_t share = ((uint64_t)target_work * n_dangling + n_valid - 1) / n_valid;
+        geo.nd_cap = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(16, (share + 15) / 16 * 16));
+    }
+    {
+        // f64 workgroups: one per CU unless the rows of a workgroup would not fit its LDS accumulators
+        // (12288 rows plus the slack below stay under 160 KiB of f64 accumulators)
+        const uint32_t n_groups = geo.rows_cap / BLOCK_GROUP, rb_max = 12288;
+        const uint32_t per_round = opt.f64_blocks ? opt.f64_blocks : 256;
+        uint32_t B = std::max<uint32_t>(1, std::min<uint32_t>(per_round, n_groups));
+        const uint32_t need = (geo.rows_cap + rb_max - 1) / rb_max;
+        // more than one workgroup per CU: whole rounds, so that the last round is as full as the first
+        if (need > B) B = (need + per_round - 1) / per_round * per_round;
+        geo.f64_blocks = B;
+        // a quarter more accumulator slots than an even deal needs: workgroups holding light rows
+        // take more 64-row groups than those holding heavy ones
+        const uint32_t even = (n_groups + B - 1) / B;
+        geo.f64_rb = (even + even / 4 + 2) * BLOCK_GROUP;
+        geo.f64_dblocks = dangling_blocks(B, geo.f64_rb / BLOCK_GROUP, geo.n_dangling_pad / BLOCK_GROUP / G);
+        geo.nd_cap = std::max<uint32_t>(geo.nd_cap, (geo.f64_dblocks + 15) / 16 * 16);
+        // exact blocked sweep: whole rounds of 256 workgroups of about 2048 rows (64 bytes of LDS per row); only
+        // where it was measured to pay
+        geo.fr_blocks = geo.fr_rb = geo.fr_dblocks = geo.fr_compact = 0;
+        bool bytes_only = values_are_u32 && !getenv("ET_FR_ROW_PER_LANE");
+        // from 16K rows per share upwards the sweep wins at every size and share count measured (16K peers: 19 against
+        // 30 us per iteration; one of eight shares of 16M peers: 421 against 588 us); the knobs move the bounds for tests
+        const uint32_t win_hi = getenv("ET_FR_SWEEP_MAX_ROWS") ? (uint32_t)atoll(getenv("ET_FR_SWEEP_MAX_ROWS")) : 0xFFFFFFFFu;
+        const uint32_t win_lo = getenv("ET_FR_SWEEP_MIN_ROWS") ? (uint32_t)atoll(getenv("ET_FR_SWEEP_MIN_ROWS")) : (1u << 14);
+        const bool window = geo.rows_cap >= win_lo && geo.rows_cap <= win_hi;
+        bytes_only = bytes_only && st.value_max <= 255;
+        if (bytes_only && window) {
+            // whole rounds of 256 workgroups (one per CU), as few as the rows' LDS footprint allows: every round
+            // pulls the whole vector through every L2 again
+            const bool compact = !getenv("ET_FR_WIDE_ROWS");          // measurement knob: the 64-byte rows
+            const uint32_t rb_max = compact ? FR_RB_MAX_COMPACT : FR_RB_MAX_WIDE;
+            uint32_t Bf = 256;
+            while ((n_groups + Bf - 1) / Bf * BLOCK_GROUP > rb_max) Bf += 256;
+            const uint32_t even_f = (n_groups + Bf - 1) / Bf;
+            // no spare accumulator slots: every workgroup holds exactly its share of the row groups (the deal still
+            // levels the edges to about 2 %), so that its 1024 threads finish the rows in full passes
+            geo.fr_blocks = Bf;
+            geo.fr_rb = even_f * BLOCK_GROUP;
+            geo.fr_compact = compact ? 1u : 0u;
+            geo.fr_dblocks = dangling_blocks(Bf, geo.fr_rb / BLOCK_GROUP, geo.n_dangling_pad / BLOCK_GROUP / G);
+            geo.nd_cap = std::max<uint32_t>(geo.nd_cap, (geo.fr_dblocks + 15) / 16 * 16);
+        }
+    }
+    geo.n_chunks = 1;
+    geo.chunk_rows = geo.rows_cap;
+    if (opt.n_chunks > 1 && geo.fr_blocks != 0) {
+        const uint32_t K = std::min<uint32_t>(opt.n_chunks, 8);
+        const uint32_t cr = round_up((geo.rows_cap + K - 1) / K, 64);
+        if ((uint64_t)(K - 1) * cr < geo.rows_cap) { geo.n_chunks = K; geo.chunk_rows = cr; }
+    }
+    g.geo = geo;
+    if (G > 8 || geo.seg_stride() >= COL_LOCAL_MASK) {
+        err = "more than 8 segments or more than 2^29 rows per segment";
+        return ET_E_UNSUPPORTED;
+    }
+    Pos P{G, geo.seg_stride()};
+    // q (global sorted row incl. class padding) of the i-th entry of `order`
+    auto q_of_rank = [&](uint32_t r) { return r < n_active ? r : geo.n_active_pad + (r - n_active); };
+    g.pos_of_ext.assign(n, 0xFFFFFFFFu);
+    for (uint32_t r = 0; r < n_valid; ++r) g.pos_of_ext[order[r]] = P.pos_of(q_of_rank(r));
+
+    return ET_OK;
+}
+
+// Step 6: inv(row sum) * 2^576 and 1 / row sum at the positions of the given active peers (native.rs:308), one batch inversion
+// per host thread; inv(n_valid - 1) * 2^288.
+template <typename SumFr, typename InvF64>
+static void fill_factors(HostGraph& g, const uint32_t* peers, uint32_t count, SumFr sum_of, InvF64 inv_f64_of) {
+    const size_t vec_len = (size_t)g.geo.n_seg * g.geo.seg_stride();
+    g.scale_fr.assign(vec_len, FrRaw{{0, 0, 0, 0}});
+    g.scale_f64.assign(vec_len, 0.0);
+    const Fr two576 = Fr::one().pow2k(576);
+    const unsigned T6 = host_threads();
+    run_threads(T6, [&](unsigned t) {
+        const uint32_t r0 = (uint32_t)((uint64_t)count * t / T6), r1 = (uint32_t)((uint64_t)count * (t + 1) / T6);
+        std::vector<Fr> inv(r1 - r0);
+        for (uint32_t r = r0; r < r1; ++r) inv[r - r0] = sum_of(peers[r]);
+        fr_batch_invert(inv);
+        for (uint32_t r = r0; r < r1; ++r) {
+            const uint32_t i = peers[r], p = g.pos_of_ext[i];
+            g.scale_fr[p] = (inv[r - r0] * two576).to_raw();
+            g.scale_f64[p] = inv_f64_of(i);
+        }
+    });
+    g.inv_nm1_w = (Fr::from_u64(g.n_valid - 1).invert_or_zero() * Fr::one().pow2k(288)).to_raw();
+}
+
+void fill_factors_u64(HostGraph& g, const uint32_t* peers, uint32_t count, const uint64_t* row_sum) {
+    fill_factors(g, peers, count, [&](uint32_t i) { return Fr::from_u64(row_sum[i]); }, [&](uint32_t i) { return 1.0 / (double)row_sum[i]; });
+}
+
+// Steps 1-4 of the plan over the attestations given: filter, last write wins, row sums, degrees.  `locally_dangling` marks
+// the members whose opinions here sum to zero (all of them, for a peer without attestations in this list).
+int filter_edges(const BuildInput& in, PlanCommon& pc, RowSums& sums, PeerStats& st, std::string& err) {
     HostGraph& g = pc.g;
     const uint32_t n = in.n;
     if (n == 0 || (in.n_edges && (!in.from || !in.to)) || ((in.val_u32 != nullptr) == (in.val_fr != nullptr) && in.n_edges)) {
         err = "bad build input";
-        return ET_E_INVALID_ARG;
-    }
-    if (opt.n_seg == 0 || opt.seg >= opt.n_seg) {
-        err = "bad segment";
         return ET_E_INVALID_ARG;
     }
     g = HostGraph();
@@ -88,16 +227,17 @@ int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& pc, std:
             if (in.to[kept[k]] == in.to[kept[k + 1]]) drop[k] = 1;  // an equal later one follows
     }
     // ---- 3. row sums: in the field (dangling test, native.rs:263-264) and as integers -------
-    std::vector<Fr> sum_fr;
-    std::vector<uint64_t> sum_u64;
-    std::vector<long double> sum_ld;
+    std::vector<Fr>& sum_fr = sums.fr;
+    std::vector<uint64_t>& sum_u64 = sums.u64;
+    std::vector<long double>& sum_ld = sums.ld;
     if (g.values_are_u32) sum_u64.assign(n, 0);
     else { sum_fr.assign(n, Fr::zero()); sum_ld.assign(n, 0.0L); }
+    uint32_t vmax = 0;                                   // largest surviving integer opinion
     for (uint32_t f = 0; f < n; ++f) {
         for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
             if (drop[k]) continue;
             uint64_t e = kept[k];
-            if (g.values_are_u32) sum_u64[f] += in.val_u32[e];
+            if (g.values_are_u32) { sum_u64[f] += in.val_u32[e]; vmax = std::max(vmax, in.val_u32[e]); }
             else {
                 const FrRaw& v = in.val_fr[e];
                 if (!fr_raw_is_canonical(v.l)) {
@@ -111,212 +251,214 @@ int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& pc, std:
     }
     std::vector<uint8_t>& dangling = pc.dangling;
     dangling.assign(n, 0);
-    uint32_t n_dangling = 0;
     for (uint32_t i = 0; i < n; ++i) {
         if (!is_member(i)) continue;
         bool zero = g.values_are_u32 ? sum_u64[i] == 0 : sum_fr[i].is_zero();
-        if (zero) { dangling[i] = 1; ++n_dangling; }
+        if (zero) dangling[i] = 1;
     }
     // ---- 4. degrees over surviving edges -----------------------------------------------------
-    std::vector<uint32_t> in_deg(n, 0), out_deg(n, 0);
+    st.in_deg.assign(n, 0);
+    st.out_deg.assign(n, 0);
+    st.value_max = vmax;
     uint64_t nnz = 0;
     for (uint32_t f = 0; f < n; ++f) {
         if (dangling[f]) continue;
         for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
             if (drop[k]) continue;
-            in_deg[in.to[kept[k]]]++;
-            out_deg[f]++;
+            st.in_deg[in.to[kept[k]]]++;
+            st.out_deg[f]++;
             ++nnz;
         }
     }
     g.nnz = nnz;
-    // ---- 5. global row order ------------------------------------------------------------------
-    // Active peers: the opt.hot_prefix most-gathered (highest out-degree), then the rest; inside each
-    // group by in-degree (descending) so that the 64 rows of a slice have similar lengths.  Dangling
-    // peers follow.
-    const uint32_t n_active = n_valid - n_dangling;
-    std::vector<uint32_t>& order = pc.order;
-    order.clear();
-    order.reserve(n_valid);
-    for (uint32_t i = 0; i < n; ++i) if (is_member(i) && !dangling[i]) order.push_back(i);
-    for (uint32_t i = 0; i < n; ++i) if (is_member(i) && dangling[i]) order.push_back(i);
-    auto by_deg = [&](uint32_t a, uint32_t b) {
-        if (in_deg[a] != in_deg[b]) return in_deg[a] > in_deg[b];
-        if (out_deg[a] != out_deg[b]) return out_deg[a] > out_deg[b];
-        return a < b;
-    };
-    auto by_out = [&](uint32_t a, uint32_t b) {
-        if (out_deg[a] != out_deg[b]) return out_deg[a] > out_deg[b];
-        return a < b;
-    };
-    {
-        const uint32_t h1 = std::min<uint32_t>(n_active, opt.hot_prefix);
-        auto b = order.begin();
-        if (h1 < n_active) std::nth_element(b, b + h1, b + n_active, by_out);
-        std::sort(b, b + h1, by_deg);
-        std::sort(b + h1, b + n_active, by_deg);
-    }
-    std::sort(order.begin() + n_active, order.end(), by_deg);
-
-    const uint32_t G = opt.n_seg;
-    Geometry geo{};
-    geo.n_seg = G;
-    geo.seg = opt.seg;
-    geo.n_active = n_active;
-    geo.n_active_pad = round_up(n_active, 64 * G);
-    geo.n_dangling = n_dangling;
-    geo.n_dangling_pad = round_up(n_dangling, 64 * G);
-    geo.rows_cap = (geo.n_active_pad + geo.n_dangling_pad) / G;
-    // one partial-sum slot per wavefront that owns dangling rows; the count depends only on global
-    // quantities so that every segment derives the same geometry
-    const uint32_t target_work = opt.target_work ? opt.target_work : 16384;
-    {
-        uint64_t share = ((uint64_t)target_work * n_dangling + n_valid - 1) / n_valid;
-        geo.nd_cap = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(16, (share + 15) / 16 * 16));
-    }
-    {
-        // f64 workgroups: one per CU unless the rows of a workgroup would not fit its LDS accumulators
-        // (12288 rows plus the slack below stay under 160 KiB of f64 accumulators)
-        const uint32_t n_groups = geo.rows_cap / BLOCK_GROUP, rb_max = 12288;
-        const uint32_t per_round = opt.f64_blocks ? opt.f64_blocks : 256;
-        uint32_t B = std::max<uint32_t>(1, std::min<uint32_t>(per_round, n_groups));
-        const uint32_t need = (geo.rows_cap + rb_max - 1) / rb_max;
-        // more than one workgroup per CU: whole rounds, so that the last round is as full as the first
-        if (need > B) B = (need + per_round - 1) / per_round * per_round;
-        geo.f64_blocks = B;
-        // a quarter more accumulator slots than an even deal needs: workgroups holding light rows
-        // take more 64-row groups than those holding heavy ones
-        const uint32_t even = (n_groups + B - 1) / B;
-        geo.f64_rb = (even + even / 4 + 2) * BLOCK_GROUP;
-        geo.f64_dblocks = dangling_blocks(B, geo.f64_rb / BLOCK_GROUP, geo.n_dangling_pad / BLOCK_GROUP / G);
-        geo.nd_cap = std::max<uint32_t>(geo.nd_cap, (geo.f64_dblocks + 15) / 16 * 16);
-        // exact blocked sweep: whole rounds of 256 workgroups of about 2048 rows (64 bytes of LDS per row); only
-        // where it was measured to pay
-        geo.fr_blocks = geo.fr_rb = geo.fr_dblocks = geo.fr_compact = 0;
-        bool bytes_only = in.val_u32 != nullptr && !getenv("ET_FR_ROW_PER_LANE");
-        // from 16K rows per share upwards the sweep wins at every size and share count measured (16K peers: 19 against
-        // 30 us per iteration; one of eight shares of 16M peers: 421 against 588 us); the knobs move the bounds for tests
-        const uint32_t win_hi = getenv("ET_FR_SWEEP_MAX_ROWS") ? (uint32_t)atoll(getenv("ET_FR_SWEEP_MAX_ROWS")) : 0xFFFFFFFFu;
-        const uint32_t win_lo = getenv("ET_FR_SWEEP_MIN_ROWS") ? (uint32_t)atoll(getenv("ET_FR_SWEEP_MIN_ROWS")) : (1u << 14);
-        const bool window = geo.rows_cap >= win_lo && geo.rows_cap <= win_hi;
-        if (bytes_only && window) {
-            uint32_t vmax = 0;
-            for (uint64_t k = 0; k < in.n_edges; ++k) vmax |= in.val_u32[k];
-            bytes_only = vmax <= 255;
-        }
-        if (bytes_only && window) {
-            // whole rounds of 256 workgroups (one per CU), as few as the rows' LDS footprint allows: every round
-            // pulls the whole vector through every L2 again
-            const bool compact = !getenv("ET_FR_WIDE_ROWS");          // measurement knob: the 64-byte rows
-            const uint32_t rb_max = compact ? FR_RB_MAX_COMPACT : FR_RB_MAX_WIDE;
-            uint32_t Bf = 256;
-            while ((n_groups + Bf - 1) / Bf * BLOCK_GROUP > rb_max) Bf += 256;
-            const uint32_t even_f = (n_groups + Bf - 1) / Bf;
-            // no spare accumulator slots: every workgroup holds exactly its share of the row groups (the deal still
-            // levels the edges to about 2 %), so that its 1024 threads finish the rows in full passes
-            geo.fr_blocks = Bf;
-            geo.fr_rb = even_f * BLOCK_GROUP;
-            geo.fr_compact = compact ? 1u : 0u;
-            geo.fr_dblocks = dangling_blocks(Bf, geo.fr_rb / BLOCK_GROUP, geo.n_dangling_pad / BLOCK_GROUP / G);
-            geo.nd_cap = std::max<uint32_t>(geo.nd_cap, (geo.fr_dblocks + 15) / 16 * 16);
-        }
-    }
-    geo.n_chunks = 1;
-    geo.chunk_rows = geo.rows_cap;
-    if (opt.n_chunks > 1 && geo.fr_blocks != 0) {
-        const uint32_t K = std::min<uint32_t>(opt.n_chunks, 8);
-        const uint32_t cr = round_up((geo.rows_cap + K - 1) / K, 64);
-        if ((uint64_t)(K - 1) * cr < geo.rows_cap) { geo.n_chunks = K; geo.chunk_rows = cr; }
-    }
-    g.geo = geo;
-    if (G > 8 || geo.seg_stride() >= COL_LOCAL_MASK) {
-        err = "more than 8 segments or more than 2^29 rows per segment";
-        return ET_E_UNSUPPORTED;
-    }
-    Pos P{G, geo.seg_stride()};
-    // q (global sorted row incl. class padding) of the i-th entry of `order`
-    auto q_of_rank = [&](uint32_t r) { return r < n_active ? r : geo.n_active_pad + (r - n_active); };
-    g.pos_of_ext.assign(n, 0xFFFFFFFFu);
-    for (uint32_t r = 0; r < n_valid; ++r) g.pos_of_ext[order[r]] = P.pos_of(q_of_rank(r));
-
-    // ---- 6. per-position source factors ------------------------------------------------------
-    const size_t vec_len = (size_t)G * geo.seg_stride();
-    g.scale_fr.assign(vec_len, FrRaw{{0, 0, 0, 0}});
-    g.scale_f64.assign(vec_len, 0.0);
-    {
-        // native.rs:308, one batch inversion per host thread over its share of the active peers
-        const Fr two576 = Fr::one().pow2k(576);
-        const unsigned T6 = host_threads();
-        run_threads(T6, [&](unsigned t) {
-            const uint32_t r0 = (uint32_t)((uint64_t)n_active * t / T6), r1 = (uint32_t)((uint64_t)n_active * (t + 1) / T6);
-            std::vector<Fr> inv(r1 - r0);
-            for (uint32_t r = r0; r < r1; ++r) {
-                uint32_t i = order[r];
-                inv[r - r0] = g.values_are_u32 ? Fr::from_u64(sum_u64[i]) : sum_fr[i];
-            }
-            fr_batch_invert(inv);
-            for (uint32_t r = r0; r < r1; ++r) {
-                uint32_t i = order[r];
-                uint32_t p = g.pos_of_ext[i];
-                g.scale_fr[p] = (inv[r - r0] * two576).to_raw();
-                g.scale_f64[p] = g.values_are_u32 ? 1.0 / (double)sum_u64[i] : (double)(1.0L / sum_ld[i]);
-            }
-        });
-        g.inv_nm1_w = (Fr::from_u64(n_valid - 1).invert_or_zero() * Fr::one().pow2k(288)).to_raw();
-    }
-
     pc.in = in;
     return ET_OK;
 }
 
-int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index, HostGraph& g, std::string& err) {
-    if (seg_index >= pc.g.geo.n_seg) { err = "bad segment"; return ET_E_INVALID_ARG; }
-    // everything that does not depend on the segment: filter results, order, positions, factors
-    g = pc.g;
-    g.geo.seg = seg_index;
-    const BuildInput& in = pc.in;
-    const uint32_t n = in.n, n_valid = g.n_valid;
-    const std::vector<uint64_t>& out_ptr = pc.out_ptr;
-    const std::vector<uint64_t>& kept = pc.kept;
-    const std::vector<uint8_t>& drop = pc.drop;
-    const std::vector<uint8_t>& dangling = pc.dangling;
-    const std::vector<uint32_t>& order = pc.order;
+int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& pc, std::string& err) {
+    if (opt.n_seg == 0 || opt.seg >= opt.n_seg) {
+        err = "bad segment";
+        return ET_E_INVALID_ARG;
+    }
+    RowSums sums;
+    PeerStats st;
+    int rc = filter_edges(in, pc, sums, st, err);
+    if (rc) return rc;
+    HostGraph& g = pc.g;
+    if ((rc = layout_common(in.n, in.member, g.values_are_u32, pc.dangling, st, opt, g, pc.order, err))) return rc;
+    // ---- 6. per-position source factors ------------------------------------------------------
+    fill_factors(g, pc.order.data(), g.geo.n_active, [&](uint32_t i) { return g.values_are_u32 ? Fr::from_u64(sums.u64[i]) : sums.fr[i]; },
+                 [&](uint32_t i) { return g.values_are_u32 ? 1.0 / (double)sums.u64[i] : (double)(1.0L / sums.ld[i]); });
+    return ET_OK;
+}
+
+namespace {
+
+// The surviving in-edges of one share's rows as the layout below consumes them: counted per row, then visited in ascending
+// order of the source's visit key (position; piece by piece with a chunked exchange) in T contiguous chunks of the order.
+// visit(local row, source code (segment << 29 | local row), handle); the handle fetches the edge's value.
+
+// ... from the attestation list itself (one process holds all of it): attesters are walked in visit order.
+struct AttesterWalk {
+    const PlanCommon& pc;
+    const HostGraph& g;
+    unsigned T;
+    std::vector<uint32_t> lr_of_edge;   // local row of edge k's destination, ~0 = dropped or another segment's
+    std::vector<uint32_t> by_pos;       // active attesters in visit order
+    std::vector<uint32_t> chunk_cut;    // T + 1 cuts of by_pos with about equal edge counts
+
+    AttesterWalk(const PlanCommon& pc_, const HostGraph& g_, unsigned T_) : pc(pc_), g(g_), T(T_) {
+        const Geometry& geo = g.geo;
+        const BuildInput& in = pc.in;
+        const uint32_t my_base = geo.seg * geo.seg_stride();
+        const uint64_t n_kept = pc.out_ptr[in.n];
+        lr_of_edge.resize(n_kept);
+        run_threads(T, [&](unsigned t) {
+            for (uint64_t k = n_kept * t / T; k < n_kept * (t + 1) / T; ++k) {
+                uint32_t lr = 0xFFFFFFFFu;
+                if (!pc.drop[k]) {
+                    const uint32_t p = g.pos_of_ext[in.to[pc.kept[k]]];
+                    if (p >= my_base && p < my_base + geo.rows_cap) lr = p - my_base;
+                }
+                lr_of_edge[k] = lr;
+            }
+        });
+        by_pos.assign(pc.order.begin(), pc.order.begin() + geo.n_active);
+        auto visit_key = [&](uint32_t ext) -> uint64_t {
+            const uint32_t p = g.pos_of_ext[ext];
+            return ((uint64_t)(geo.n_chunks > 1 ? geo.chunk_of_local(p % geo.seg_stride()) : 0u) << 32) | p;
+        };
+        std::sort(by_pos.begin(), by_pos.end(), [&](uint32_t a, uint32_t b) { return visit_key(a) < visit_key(b); });
+        const uint32_t n_active = geo.n_active;
+        std::vector<uint64_t> pos_edges((size_t)n_active + 1, 0);
+        for (uint32_t i = 0; i < n_active; ++i) pos_edges[i + 1] = pos_edges[i] + (pc.out_ptr[by_pos[i] + 1] - pc.out_ptr[by_pos[i]]);
+        chunk_cut.assign(T + 1, n_active);
+        chunk_cut[0] = 0;
+        for (unsigned t = 1; t < T; ++t)
+            chunk_cut[t] = (uint32_t)(std::lower_bound(pos_edges.begin(), pos_edges.end(), pos_edges[n_active] * t / T) - pos_edges.begin());
+        for (unsigned t = 1; t <= T; ++t) chunk_cut[t] = std::min<uint32_t>(n_active, std::max(chunk_cut[t], chunk_cut[t - 1]));
+        chunk_cut[T] = n_active;
+    }
+    void count_rows(std::vector<uint64_t>& in_ptr) const {
+        const uint32_t n = pc.in.n;
+        run_threads(T, [&](unsigned t) {
+            for (uint32_t f = (uint32_t)((uint64_t)n * t / T); f < (uint32_t)((uint64_t)n * (t + 1) / T); ++f) {
+                if (pc.dangling[f]) continue;
+                for (uint64_t k = pc.out_ptr[f]; k < pc.out_ptr[f + 1]; ++k) {
+                    const uint32_t lr = lr_of_edge[k];
+                    if (lr != 0xFFFFFFFFu) __atomic_fetch_add(&in_ptr[lr + 1], 1, __ATOMIC_RELAXED);
+                }
+            }
+        });
+    }
+    template <typename V>
+    void walk(unsigned t, V visit) const {
+        const Geometry& geo = g.geo;
+        for (uint32_t i = chunk_cut[t]; i < chunk_cut[t + 1]; ++i) {
+            const uint32_t f = by_pos[i];
+            uint32_t pf = g.pos_of_ext[f];
+            pf = ((pf / geo.seg_stride()) << COL_SEG_SHIFT) | (pf % geo.seg_stride());
+            for (uint64_t k = pc.out_ptr[f]; k < pc.out_ptr[f + 1]; ++k) {
+                const uint32_t lr = lr_of_edge[k];
+                if (lr != 0xFFFFFFFFu) visit(lr, pf, pc.kept[k]);
+            }
+        }
+    }
+    uint32_t value_u32(uint64_t h) const { return pc.in.val_u32[h]; }
+    const FrRaw& value_fr(uint64_t h) const { return pc.in.val_fr[h]; }
+};
+
+// ... from edge records that other processes sent: (source code, local row, integer opinion), any order on arrival
+struct RecordWalk {
+    const Geometry geo;
+    unsigned T;
+    uint64_t count;
+    std::vector<uint32_t> src, row, val;   // sorted by the source's visit key
+
+    RecordWalk(const Geometry& geo_, unsigned T_, const std::vector<uint32_t>& src_in, const std::vector<uint32_t>& row_in,
+               const std::vector<uint32_t>& val_in) : geo(geo_), T(T_), count(src_in.size()) {
+        // sort by visit key: T buckets of equal key ranges (sources are spread evenly over the positions), each sorted by its owner
+        const uint64_t key_end = ((uint64_t)geo.n_chunks << 32);
+        auto key_of = [&](uint32_t code) -> uint64_t {
+            const uint32_t local = code & COL_LOCAL_MASK;
+            return ((uint64_t)(geo.n_chunks > 1 ? geo.chunk_of_local(local) : 0u) << 32) | geo.pos_of_col(code);
+        };
+        // bucket = position of the key in [0, key_end) taken over (piece, position / vector length)
+        const uint64_t vec_len = (uint64_t)geo.n_seg * geo.seg_stride();
+        auto bucket_of = [&](uint64_t key) -> unsigned {
+            const long double frac = ((long double)(key >> 32) + (long double)(key & 0xFFFFFFFFull) / (long double)vec_len) / (long double)geo.n_chunks;
+            return (unsigned)std::min<long double>(T - 1, frac * T);
+        };
+        (void)key_end;
+        std::vector<uint64_t> cnt((size_t)T * T, 0);
+        run_threads(T, [&](unsigned t) {
+            for (uint64_t k = count * t / T; k < count * (t + 1) / T; ++k) ++cnt[(size_t)t * T + bucket_of(key_of(src_in[k]))];
+        });
+        std::vector<uint64_t> begin(T + 1, 0);
+        {
+            uint64_t run = 0;
+            for (unsigned d = 0; d < T; ++d) {
+                begin[d] = run;
+                for (unsigned t = 0; t < T; ++t) { const uint64_t c = cnt[(size_t)t * T + d]; cnt[(size_t)t * T + d] = run; run += c; }
+            }
+            begin[T] = run;
+        }
+        struct Rec { uint64_t key; uint32_t row, val; };
+        std::vector<Rec> buf(count);
+        run_threads(T, [&](unsigned t) {
+            for (uint64_t k = count * t / T; k < count * (t + 1) / T; ++k) {
+                const uint64_t key = key_of(src_in[k]);
+                buf[cnt[(size_t)t * T + bucket_of(key)]++] = Rec{key, row_in[k], val_in[k]};
+            }
+        });
+        run_threads(T, [&](unsigned d) {
+            std::sort(buf.begin() + begin[d], buf.begin() + begin[d + 1], [](const Rec& a, const Rec& b) {
+                if (a.key != b.key) return a.key < b.key;
+                return a.row < b.row;
+            });
+        });
+        src.resize(count); row.resize(count); val.resize(count);
+        const uint32_t stride = geo.seg_stride();
+        run_threads(T, [&](unsigned t) {
+            for (uint64_t k = count * t / T; k < count * (t + 1) / T; ++k) {
+                const uint32_t pos = (uint32_t)(buf[k].key & 0xFFFFFFFFull);
+                src[k] = ((pos / stride) << COL_SEG_SHIFT) | (pos % stride);
+                row[k] = buf[k].row;
+                val[k] = buf[k].val;
+            }
+        });
+    }
+    void count_rows(std::vector<uint64_t>& in_ptr) const {
+        run_threads(T, [&](unsigned t) {
+            for (uint64_t k = count * t / T; k < count * (t + 1) / T; ++k) __atomic_fetch_add(&in_ptr[row[k] + 1], 1, __ATOMIC_RELAXED);
+        });
+    }
+    template <typename V>
+    void walk(unsigned t, V visit) const {
+        for (uint64_t k = count * t / T; k < count * (t + 1) / T; ++k) visit(row[k], src[k], k);
+    }
+    uint32_t value_u32(uint64_t h) const { return val[h]; }
+    const FrRaw& value_fr(uint64_t) const { static const FrRaw zero{{0, 0, 0, 0}}; return zero; }   // records carry integer opinions only
+};
+
+// Steps 7-10: one share's edge lists.  `g` holds the common part (geometry with geo.seg set, positions, factors).
+template <class Src>
+int lay_out_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned T, std::string& err) {
     const Geometry geo = g.geo;
+    const uint32_t seg_index = geo.seg;
     const uint32_t G = geo.n_seg, n_active = geo.n_active, n_dangling = geo.n_dangling;
     const uint32_t target_work = opt.target_work ? opt.target_work : 16384;
-    (void)n_valid;
     // ---- 7. in-edges of this segment's rows, sources ascending by position -------------------
-    // local row of an external peer, or ~0 when it lives in another segment
-    const uint32_t my_base = seg_index * geo.seg_stride();
-    auto local_row = [&](uint32_t ext) -> uint32_t {
-        uint32_t p = g.pos_of_ext[ext];
-        if (p < my_base || p >= my_base + geo.rows_cap) return 0xFFFFFFFFu;
-        return p - my_base;
-    };
     // The passes below scatter every surviving edge by destination row; they run on several host
     // threads, each owning a contiguous range of rows (or of workgroups), so that no two threads
     // write the same counter and every thread emits its edges in the same, source-ascending order.
-    const unsigned T = host_threads();
-    const uint64_t n_kept = out_ptr[n];
-    std::vector<uint32_t> lr_of_edge(n_kept);   // local row of edge k's destination, ~0 = dropped or another segment's
-    run_threads(T, [&](unsigned t) {
-        for (uint64_t k = n_kept * t / T; k < n_kept * (t + 1) / T; ++k) lr_of_edge[k] = drop[k] ? 0xFFFFFFFFu : local_row(in.to[kept[k]]);
-    });
     std::vector<uint64_t> in_ptr((size_t)geo.rows_cap + 1, 0);
-    run_threads(T, [&](unsigned t) {
-        for (uint32_t f = (uint32_t)((uint64_t)n * t / T); f < (uint32_t)((uint64_t)n * (t + 1) / T); ++f) {
-            if (dangling[f]) continue;
-            for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
-                const uint32_t lr = lr_of_edge[k];
-                if (lr != 0xFFFFFFFFu) __atomic_fetch_add(&in_ptr[lr + 1], 1, __ATOMIC_RELAXED);
-            }
-        }
-    });
+    src.count_rows(in_ptr);
     for (uint32_t i = 0; i < geo.rows_cap; ++i) in_ptr[i + 1] += in_ptr[i];
     g.nnz_local = in_ptr[geo.rows_cap];
     const bool per_row_stream = geo.fr_blocks == 0;      // else the exact variant runs the blocked sweep too
     std::vector<uint32_t> e_src(per_row_stream ? g.nnz_local : 0);   // source, encoded (segment << 29) | local row
-    std::vector<uint64_t> e_idx(per_row_stream ? g.nnz_local : 0);   // original edge index (for the value)
+    std::vector<uint64_t> e_idx(per_row_stream ? g.nnz_local : 0);   // the edge's value handle
     // The same edges grouped by workgroup of the f64 blocked sweep, ascending by source.  The row
     // groups are handed out heaviest first, each to the workgroup with the fewest edges so far that
     // still has a free accumulator slot: a launch ends with its slowest workgroup, so edge counts
@@ -362,43 +504,15 @@ int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index,
     if (g.values_are_u32) g.bk_val_u32.resize(g.nnz_local);
     else g.bk_val_fr.resize(g.nnz_local);
     {
-        // visit attesters in ascending POSITION so that every row's (and every workgroup's) sources
-        // come out sorted
         std::vector<uint64_t> cur(in_ptr.begin(), in_ptr.end() - 1);
         std::vector<uint64_t> bcur(g.bk_ptr.begin(), g.bk_ptr.end() - 1);
-        std::vector<uint32_t> by_pos(order.begin(), order.begin() + n_active);
-        // ascending position; with a chunked exchange, piece by piece (piece q of every segment before piece q + 1 of any)
-        auto visit_key = [&](uint32_t ext) -> uint64_t {
-            const uint32_t p = g.pos_of_ext[ext];
-            return ((uint64_t)(geo.n_chunks > 1 ? geo.chunk_of_local(p % geo.seg_stride()) : 0u) << 32) | p;
-        };
-        std::sort(by_pos.begin(), by_pos.end(), [&](uint32_t a, uint32_t b) { return visit_key(a) < visit_key(b); });
-        // Every thread walks ONE contiguous chunk of the attesters (ascending position, chunks of equal edge count)
-        // and drops each surviving edge into the bucket of the thread that owns its destination; a bucket therefore
-        // holds its edges in ascending source order, and its owner appends them to the rows (or workgroups) it owns.
-        std::vector<uint64_t> pos_edges((size_t)n_active + 1, 0);
-        for (uint32_t i = 0; i < n_active; ++i) pos_edges[i + 1] = pos_edges[i] + (out_ptr[by_pos[i] + 1] - out_ptr[by_pos[i]]);
-        std::vector<uint32_t> chunk_cut(T + 1, n_active);
-        chunk_cut[0] = 0;
-        for (unsigned t = 1; t < T; ++t)
-            chunk_cut[t] = (uint32_t)(std::lower_bound(pos_edges.begin(), pos_edges.end(), pos_edges[n_active] * t / T) - pos_edges.begin());
-        for (unsigned t = 1; t <= T; ++t) chunk_cut[t] = std::min<uint32_t>(n_active, std::max(chunk_cut[t], chunk_cut[t - 1]));
-        chunk_cut[T] = n_active;
-        struct Entry { uint32_t lr, pf; uint64_t k; };
+        // Every thread walks ONE contiguous chunk of the visit order and drops each edge into the bucket of the thread that
+        // owns its destination; a bucket therefore holds its edges in ascending source order, and its owner appends them to
+        // the rows (or workgroups) it owns.
+        struct Entry { uint32_t lr, pf; uint64_t h; };
         auto scatter = [&](auto bucket_of, auto consume) {
             std::vector<uint64_t> cnt((size_t)T * T, 0);
-            auto walk = [&](unsigned t, auto visit) {
-                for (uint32_t i = chunk_cut[t]; i < chunk_cut[t + 1]; ++i) {
-                    const uint32_t f = by_pos[i];
-                    uint32_t pf = g.pos_of_ext[f];
-                    pf = ((pf / geo.seg_stride()) << COL_SEG_SHIFT) | (pf % geo.seg_stride());
-                    for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
-                        const uint32_t lr = lr_of_edge[k];
-                        if (lr != 0xFFFFFFFFu) visit(lr, pf, k);
-                    }
-                }
-            };
-            run_threads(T, [&](unsigned t) { walk(t, [&](uint32_t lr, uint32_t, uint64_t) { ++cnt[(size_t)t * T + bucket_of(lr)]; }); });
+            run_threads(T, [&](unsigned t) { src.walk(t, [&](uint32_t lr, uint32_t, uint64_t) { ++cnt[(size_t)t * T + bucket_of(lr)]; }); });
             std::vector<uint64_t> bucket_begin(T + 1, 0);
             {
                 uint64_t run = 0;
@@ -409,7 +523,7 @@ int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index,
                 bucket_begin[T] = run;
             }
             std::vector<Entry> buf(bucket_begin[T]);
-            run_threads(T, [&](unsigned t) { walk(t, [&](uint32_t lr, uint32_t pf, uint64_t k) { buf[cnt[(size_t)t * T + bucket_of(lr)]++] = Entry{lr, pf, k}; }); });
+            run_threads(T, [&](unsigned t) { src.walk(t, [&](uint32_t lr, uint32_t pf, uint64_t h) { buf[cnt[(size_t)t * T + bucket_of(lr)]++] = Entry{lr, pf, h}; }); });
             run_threads(T, [&](unsigned d) { for (uint64_t i = bucket_begin[d]; i < bucket_begin[d + 1]; ++i) consume(buf[i]); });
         };
         // (a) per-row lists: thread t owns the rows whose edges fall in its share of the edge count
@@ -424,7 +538,7 @@ int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index,
                     [&](const Entry& e) {
                         const uint64_t p = cur[e.lr]++;
                         e_src[p] = e.pf;
-                        e_idx[p] = kept[e.k];
+                        e_idx[p] = e.h;
                     });
         // (b) per-workgroup lists: thread t owns a contiguous range of workgroups
         const uint32_t B64 = geo.f64_blocks;
@@ -437,8 +551,8 @@ int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index,
                     const uint64_t q = bcur[d64.block[grp]]++;
                     g.bk_col[q] = e.pf;
                     g.bk_row[q] = (uint16_t)(d64.slot[grp] * BLOCK_GROUP + e.lr % BLOCK_GROUP);
-                    if (g.values_are_u32) g.bk_val_u32[q] = in.val_u32[kept[e.k]];
-                    else g.bk_val_fr[q] = in.val_fr[kept[e.k]];
+                    if (g.values_are_u32) g.bk_val_u32[q] = src.value_u32(e.h);
+                    else g.bk_val_fr[q] = src.value_fr(e.h);
                 });
         // (c) the workgroups of the exact blocked sweep, when the geometry asks for them
         if (geo.fr_blocks) {
@@ -457,7 +571,7 @@ int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index,
                         const uint64_t q = fcur[dfr.block[grp]]++;
                         g.fb_col[q] = e.pf;
                         g.fb_row[q] = (uint16_t)(dfr.slot[grp] * BLOCK_GROUP + e.lr % BLOCK_GROUP);
-                        g.fb_val[q] = (uint8_t)in.val_u32[kept[e.k]];
+                        g.fb_val[q] = (uint8_t)src.value_u32(e.h);
                     });
         }
     }
@@ -559,8 +673,8 @@ int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index,
                 const uint64_t j = k - b;
                 size_t slot = ((size_t)sd.off + j / lanes) * 64 + ((size_t)l << sh) + j % lanes;
                 g.col[slot] = e_src[k];
-                if (g.values_are_u32) g.val_u32[slot] = in.val_u32[e_idx[k]];
-                else g.val_fr[slot] = in.val_fr[e_idx[k]];
+                if (g.values_are_u32) g.val_u32[slot] = src.value_u32(e_idx[k]);
+                else g.val_fr[slot] = src.value_fr(e_idx[k]);
             }
         }
       }
@@ -597,6 +711,33 @@ int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index,
         return ET_E_UNSUPPORTED;
     }
     return ET_OK;
+}
+
+}  // namespace
+
+int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index, HostGraph& g, std::string& err) {
+    if (seg_index >= pc.g.geo.n_seg) { err = "bad segment"; return ET_E_INVALID_ARG; }
+    // everything that does not depend on the segment: filter results, order, positions, factors
+    g = pc.g;
+    g.geo.seg = seg_index;
+    const unsigned T = host_threads();
+    AttesterWalk src(pc, g, T);
+    return lay_out_segment(g, opt, src, T, err);
+}
+
+int plan_segment_from_records(HostGraph& g, const BuildOpts& opt, uint32_t seg_index, const std::vector<uint32_t>& src_code,
+                              const std::vector<uint32_t>& row, const std::vector<uint32_t>& val, std::string& err) {
+    if (seg_index >= g.geo.n_seg) { err = "bad segment"; return ET_E_INVALID_ARG; }
+    if (!g.values_are_u32) { err = "edge records carry integer opinions only"; return ET_E_UNSUPPORTED; }
+    if (src_code.size() != row.size() || row.size() != val.size()) { err = "edge record arrays differ in length"; return ET_E_INVALID_ARG; }
+    g.geo.seg = seg_index;
+    for (size_t k = 0; k < row.size(); ++k) {
+        const uint32_t s = src_code[k] >> COL_SEG_SHIFT, l = src_code[k] & COL_LOCAL_MASK;
+        if (row[k] >= g.geo.rows_cap || s >= g.geo.n_seg || l >= g.geo.rows_cap) { err = "edge record out of range"; return ET_E_OUT_OF_RANGE; }
+    }
+    const unsigned T = host_threads();
+    RecordWalk src(g.geo, T, src_code, row, val);
+    return lay_out_segment(g, opt, src, T, err);
 }
 
 int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::string& err) {

@@ -97,6 +97,31 @@ struct PlanCommon {
 int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& out, std::string& err);
 int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg, HostGraph& out, std::string& err);
 
+// A share laid out by a process that never sees the whole attestation list (several processes, each holding the
+// attestations of its own attesters).  The per-peer statistics are summed over the processes; every process then derives the
+// same order, geometry and positions (layout_common fills g.geo, g.pos_of_ext and `order`; g.n, g.n_valid, g.nnz and
+// g.values_are_u32 are set by the caller), sends each surviving edge to the share that owns its destination row as a record
+// (source code = (segment << 29) | local row, destination local row, integer opinion), and lays out its own share from the
+// records it received.
+struct PeerStats {
+    std::vector<uint32_t> in_deg, out_deg;   // over the surviving edges of non-dangling attesters
+    uint32_t value_max = 0;                  // bit-or of the surviving integer opinions (0 for field-valued ones)
+};
+int layout_common(uint32_t n, const uint8_t* member, bool values_are_u32, const std::vector<uint8_t>& dangling, const PeerStats& st,
+                  const BuildOpts& opt, HostGraph& g, std::vector<uint32_t>& order, std::string& err);
+// factors of the active peers listed (integer row sums); positions outside the list keep zero factors
+void fill_factors_u64(HostGraph& g, const uint32_t* peers, uint32_t count, const uint64_t* row_sum);
+// `g` holds the common part on entry (layout_common + fill_factors_u64) and the share's plan on return
+int plan_segment_from_records(HostGraph& g, const BuildOpts& opt, uint32_t seg, const std::vector<uint32_t>& src_code,
+                              const std::vector<uint32_t>& row, const std::vector<uint32_t>& val, std::string& err);
+// steps 1-4 alone (filter, last write wins, row sums, degrees) over the attestations given
+struct RowSums {
+    std::vector<uint64_t> u64;          // integer opinions
+    std::vector<Fr> fr;                 // field-valued opinions: in the field ...
+    std::vector<long double> ld;        // ... and as real numbers, for the f64 variant
+};
+int filter_edges(const BuildInput& in, PlanCommon& pc, RowSums& sums, PeerStats& st, std::string& err);
+
 // host threads for the scatter passes over the edges (the GPU boxes give a process 16 CPUs)
 inline unsigned host_threads() {
     unsigned hw = std::thread::hardware_concurrency();
@@ -114,3 +139,8 @@ inline void run_threads(unsigned count, F f) {
 }
 
 }  // namespace et
+
+// the C ABI's host-side plan handle (et_plan_* and et_dplan_finish_host produce it)
+struct et_plan {
+    et::HostGraph h;
+};

@@ -64,10 +64,6 @@ int et_device_count(void) {
     return n;
 }
 
-struct et_plan {
-    HostGraph h;
-};
-
 static void read_opts(const et_build_opts* opts, BuildOpts& bo, int& variants, int& device) {
     variants = 0;
     device = -1;

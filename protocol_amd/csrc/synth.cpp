@@ -89,9 +89,10 @@ struct Alias {
 
 }  // namespace
 
-extern "C" int et_synth_graph(uint32_t kind, uint32_t n, uint64_t target_edges, uint64_t seed, uint32_t value_max,
-                              uint64_t* n_edges, uint32_t* from, uint32_t* to, uint32_t* value) {
-    if (!n_edges || n < 2 || value_max == 0 || (kind != 2 && kind != 3)) return ET_E_INVALID_ARG;
+extern "C" int et_synth_graph_range(uint32_t kind, uint32_t n, uint64_t target_edges, uint64_t seed, uint32_t value_max,
+                                    uint32_t attester_begin, uint32_t attester_end, uint64_t* n_edges, uint32_t* from, uint32_t* to,
+                                    uint32_t* value) {
+    if (!n_edges || n < 2 || value_max == 0 || (kind != 2 && kind != 3) || attester_begin > attester_end || attester_end > n) return ET_E_INVALID_ARG;
     std::vector<uint32_t> deg(n, 0);
     std::vector<double> popularity;
     if (kind == 2) {
@@ -129,15 +130,16 @@ extern "C" int et_synth_graph(uint32_t kind, uint32_t n, uint64_t target_edges, 
         popularity.resize(n);
         for (uint32_t i = 0; i < n; ++i) popularity[i] = std::sqrt((double)deg[i] + 1.0);
     }
+    // the degrees and the target distribution depend on all peers; only the attesters asked for emit their lists
     std::vector<uint64_t> off((size_t)n + 1, 0);
-    for (uint32_t i = 0; i < n; ++i) off[i + 1] = off[i] + deg[i];
+    for (uint32_t i = 0; i < n; ++i) off[i + 1] = off[i] + ((i >= attester_begin && i < attester_end) ? deg[i] : 0u);
     *n_edges = off[n];
     if (!from || !to || !value) return ET_OK;
     Alias alias;
     if (kind == 3) alias.build(popularity);
     parallel_for(n, [&](uint32_t i) {
         uint32_t d = deg[i];
-        if (d == 0) return;
+        if (d == 0 || i < attester_begin || i >= attester_end) return;
         Xoshiro r(seed, (uint64_t)i * 2 + 2);
         std::vector<uint32_t> t;
         t.reserve((size_t)d * 2);
@@ -171,4 +173,9 @@ extern "C" int et_synth_graph(uint32_t kind, uint32_t n, uint64_t target_edges, 
         }
     });
     return ET_OK;
+}
+
+extern "C" int et_synth_graph(uint32_t kind, uint32_t n, uint64_t target_edges, uint64_t seed, uint32_t value_max,
+                              uint64_t* n_edges, uint32_t* from, uint32_t* to, uint32_t* value) {
+    return et_synth_graph_range(kind, n, target_edges, seed, value_max, 0, n, n_edges, from, to, value);
 }

@@ -37,6 +37,104 @@ def synth_graph(kind, n, target_edges, seed=42, value_max=255):
     return frm, to, val
 
 
+def synth_graph_range(kind, n, target_edges, attester_begin, attester_end, seed=42, value_max=255):
+    """The part of synth_graph's list that the attesters [attester_begin, attester_end) wrote (et_synth_graph_range)."""
+    ne = C.c_uint64(0)
+    check(lib().et_synth_graph_range(kind, n, target_edges, seed, value_max, attester_begin, attester_end, C.byref(ne), None, None, None))
+    frm = np.empty(ne.value, dtype=np.uint32)
+    to = np.empty(ne.value, dtype=np.uint32)
+    val = np.empty(ne.value, dtype=np.uint32)
+    check(lib().et_synth_graph_range(kind, n, target_edges, seed, value_max, attester_begin, attester_end, C.byref(ne),
+                                     _ptr(frm), _ptr(to), _ptr(val)))
+    return frm, to, val
+
+
+class DistributedPlan:
+    """One share laid out from the attestations of this process's own attesters (et_dplan_*).  The caller moves the
+    statistics and the edge records between the processes; see ShardedGraph for the torch.distributed way."""
+
+    def __init__(self, n, frm, to, value_u32, member=None):
+        frm = np.ascontiguousarray(frm, dtype=np.uint32)
+        to = np.ascontiguousarray(to, dtype=np.uint32)
+        value_u32 = np.ascontiguousarray(value_u32, dtype=np.uint32)
+        if not (len(frm) == len(to) == len(value_u32)):
+            raise ValueError("from/to/value length mismatch")
+        if member is not None:
+            member = np.ascontiguousarray(member, dtype=np.uint8)
+            if len(member) != n:
+                raise ValueError("member flags must have n entries")
+        h = C.c_void_p()
+        check(lib().et_dplan_create(n, _ptr(member), len(frm), _ptr(frm), _ptr(to), _ptr(value_u32), C.byref(h)))
+        self._h = h
+        self.n = n
+        self.n_seg = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().et_dplan_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def local_stats(self):
+        """(row_sum uint64[n], in_degree uint32[n], out_degree uint32[n], value_max)."""
+        row_sum = np.empty(self.n, dtype=np.uint64)
+        in_deg = np.empty(self.n, dtype=np.uint32)
+        out_deg = np.empty(self.n, dtype=np.uint32)
+        vmax = C.c_uint32(0)
+        check(lib().et_dplan_local_stats(self._h, _ptr(row_sum), _ptr(in_deg), _ptr(out_deg), C.byref(vmax)))
+        return row_sum, in_deg, out_deg, vmax.value
+
+    def set_global_stats(self, row_sum, in_deg, out_deg, value_max, n_seg, seg, variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64,
+                         device=-1, n_chunks=1, long_row=0, target_work=0):
+        row_sum = np.ascontiguousarray(row_sum, dtype=np.uint64)
+        in_deg = np.ascontiguousarray(in_deg, dtype=np.uint32)
+        out_deg = np.ascontiguousarray(out_deg, dtype=np.uint32)
+        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, variants, device, n_chunks)
+        check(lib().et_dplan_set_global_stats(self._h, _ptr(row_sum), _ptr(in_deg), _ptr(out_deg), int(value_max), C.byref(opts)))
+        self.n_seg = n_seg
+
+    def outgoing(self, share):
+        """(source codes, destination local rows, opinions) for `share`: views into the plan's memory."""
+        cnt = C.c_uint64(0)
+        ps, pr, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib().et_dplan_outgoing(self._h, share, C.byref(cnt), C.byref(ps), C.byref(pr), C.byref(pv)))
+        k = cnt.value
+        if k == 0:
+            z = np.zeros(0, dtype=np.uint32)
+            return z, z, z
+        mk = lambda p: np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), (k,))
+        return mk(ps), mk(pr), mk(pv)
+
+    def add_incoming(self, src, row, val):
+        src = np.ascontiguousarray(src, dtype=np.uint32)
+        row = np.ascontiguousarray(row, dtype=np.uint32)
+        val = np.ascontiguousarray(val, dtype=np.uint32)
+        if not (len(src) == len(row) == len(val)):
+            raise ValueError("record arrays differ in length")
+        check(lib().et_dplan_add_incoming(self._h, len(src), _ptr(src), _ptr(row), _ptr(val)))
+
+    def info(self):
+        info = _ffi.EtGraphInfo()
+        check(lib().et_dplan_info_get(self._h, C.byref(info)))
+        return info
+
+    def finish(self):
+        h = C.c_void_p()
+        check(lib().et_dplan_finish(self._h, C.byref(h)))
+        return Graph._from_handle(h, self.n)
+
+    def finish_host(self):
+        """The share's host-side plan (no GPU needed)."""
+        h = C.c_void_p()
+        check(lib().et_dplan_finish_host(self._h, C.byref(h)))
+        return Plan._from_handle(h, self.n)
+
+
 class Graph:
     """A filtered, normalised attestation graph resident on one GPU."""
 
@@ -64,6 +162,16 @@ class Graph:
         info = _ffi.EtGraphInfo()
         check(lib().et_graph_info_get(self._h, C.byref(info)))
         self.info = info
+
+    @classmethod
+    def _from_handle(cls, h, n):
+        self = cls.__new__(cls)
+        self._h = h
+        self.n = n
+        info = _ffi.EtGraphInfo()
+        check(lib().et_graph_info_get(self._h, C.byref(info)))
+        self.info = info
+        return self
 
     def close(self):
         if getattr(self, "_h", None):
@@ -236,6 +344,15 @@ class Plan:
         h = C.c_void_p()
         check(lib().et_plan_build(n, _ptr(member), len(frm), _ptr(frm), _ptr(to), _ptr(value_u32),
                                   _ptr(value_fr), C.byref(opts), C.byref(h)))
+        self._load(h, n)
+
+    @classmethod
+    def _from_handle(cls, h, n):
+        self = cls.__new__(cls)
+        self._load(h, n)
+        return self
+
+    def _load(self, h, n):
         try:
             info = _ffi.EtGraphInfo()
             check(lib().et_plan_info_get(h, C.byref(info)))

@@ -17,23 +17,78 @@ import torch
 import torch.distributed as dist
 
 from . import _ffi
-from .graph import Graph, R_MODULUS
+from .graph import DistributedPlan, Graph, R_MODULUS
+
+
+def _all_reduce_np(arr, signed_view, op, group, world, comm_device):
+    """All-reduce of a numpy array of unsigned integers (summed or maximised as the signed type of the same width:
+    per-peer degree sums stay far below 2^31, row sums below 2^63)."""
+    if world == 1:
+        return arr
+    t = torch.from_numpy(arr.view(signed_view)).to(comm_device)
+    dist.all_reduce(t, op=op, group=group)
+    return t.cpu().numpy().view(arr.dtype)
+
+
+def distributed_plan(n, frm, to, value_u32, member=None, group=None, world=1, rank=0, comm_device=None, **opts):
+    """The share of `rank` laid out from rank-local attestations (every attestation of an attester on one rank), ready for
+    DistributedPlan.finish() / finish_host().  Collectives: three all-reduces of per-peer figures (8 + 4 + 4 bytes per
+    peer), one of a scalar, one all-gather of the record counts and three all-to-alls of the edge records (12 bytes per
+    surviving edge in all).  `comm_device`: where tensors handed to a collective live (the GPU for RCCL, the host for
+    gloo)."""
+    comm_device = comm_device or torch.device("cpu")
+    plan = DistributedPlan(n, frm, to, value_u32, member=member)
+    row_sum, in_deg, out_deg, vmax = plan.local_stats()
+    row_sum = _all_reduce_np(row_sum, np.int64, dist.ReduceOp.SUM, group, world, comm_device)
+    in_deg = _all_reduce_np(in_deg, np.int32, dist.ReduceOp.SUM, group, world, comm_device)
+    out_deg = _all_reduce_np(out_deg, np.int32, dist.ReduceOp.SUM, group, world, comm_device)
+    vmax = int(_all_reduce_np(np.array([vmax], dtype=np.uint32), np.int32, dist.ReduceOp.MAX, group, world, comm_device)[0])
+    plan.set_global_stats(row_sum, in_deg, out_deg, vmax, world, rank, **opts)
+    del row_sum, in_deg, out_deg
+    outgoing = [plan.outgoing(s) for s in range(world)]
+    if world == 1:
+        plan.add_incoming(*outgoing[0])
+        return plan
+    send = [len(o[0]) for o in outgoing]
+    counts = torch.tensor(send, dtype=torch.int64, device=comm_device)
+    all_counts = [torch.empty_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts, group=group)
+    recv = [int(c[rank]) for c in all_counts]                 # what every rank holds for this one
+    got = []
+    for field in range(3):                                    # source codes, destination rows, opinions
+        buf = np.concatenate([o[field] for o in outgoing])
+        t_in = torch.from_numpy(buf.view(np.int32)).to(comm_device)
+        t_out = torch.empty(sum(recv), dtype=torch.int32, device=comm_device)
+        dist.all_to_all_single(t_out, t_in, recv, send, group=group)
+        got.append(t_out.cpu().numpy().view(np.uint32))
+        del buf, t_in, t_out
+    plan.add_incoming(*got)
+    return plan
 
 
 class ShardedGraph:
     def __init__(self, n, frm, to, value_u32=None, value_fr=None, member=None, group=None,
-                 device=None, variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64, always_exchange=False, n_chunks=1, **build_kw):
+                 device=None, variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64, always_exchange=False, n_chunks=1,
+                 local_attestations=False, **build_kw):
         # always_exchange: take the stepping + all-gather path even with a single rank (the collective is then a
         # copy of the vector onto itself): the way to run the RCCL call of this driver on a one-GPU box
+        # local_attestations: frm / to / value_u32 hold only the attestations of THIS rank's attesters (every
+        # attestation of an attester on one rank); the ranks agree on the layout through three all-reduces and send
+        # each edge to the rank that owns its destination row, so that no rank ever holds the whole list
         self.always_exchange = always_exchange
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.graph = Graph(n, frm, to, value_u32=value_u32, value_fr=value_fr, member=member,
-                           n_seg=self.world, seg=self.rank, variants=variants,
-                           device=self.device.index if self.device.index is not None else -1,
-                           n_chunks=n_chunks if (self.world > 1 or always_exchange) else 1, **build_kw)
+        dev_index = self.device.index if self.device.index is not None else -1
+        chunks = n_chunks if (self.world > 1 or always_exchange) else 1
+        if local_attestations:
+            if value_fr is not None or value_u32 is None:
+                raise ValueError("attestations ingested rank by rank carry integer opinions")
+            self.graph = self._build_from_local(n, frm, to, value_u32, member, variants, dev_index, chunks, **build_kw)
+        else:
+            self.graph = Graph(n, frm, to, value_u32=value_u32, value_fr=value_fr, member=member,
+                               n_seg=self.world, seg=self.rank, variants=variants, device=dev_index, n_chunks=chunks, **build_kw)
         info = self.graph.info
         # chunked exchange: a segment travels in n_chunks pieces while the iteration's n_chunks launches run, launch q
         # waiting for piece q only (1 where the graph does not take the blocked sweeps)
@@ -46,6 +101,14 @@ class ShardedGraph:
         self.nnz = int(info.nnz)
         self.n_valid = int(info.n_valid)
         self._vec = {}
+
+    def _build_from_local(self, n, frm, to, value_u32, member, variants, dev_index, n_chunks, **build_kw):
+        comm = self.device if dist.is_initialized() and dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        plan = distributed_plan(n, frm, to, value_u32, member=member, group=self.group, world=self.world, rank=self.rank,
+                                comm_device=comm, variants=variants, device=dev_index, n_chunks=n_chunks, **build_kw)
+        graph = plan.finish()
+        plan.close()
+        return graph
 
     # ---- buffers ---------------------------------------------------------------------------------
     def _buffers(self, kind):

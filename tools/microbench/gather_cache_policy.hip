@@ -1,59 +1,116 @@
-// Microbenchmark 2: cost of random 8-byte gathers by table size and cache policy (plain / nt / sc1 / sc0 sc1).
+// Do the cache-policy bits of a global load (sc0, sc1, nt) change what a gather costs?  A miss in the vector L1 fetches a
+// whole 128-byte line for 8 or 32 useful bytes; this measures whether any policy makes the L1 ask for less.
+// Per block a sorted list of element indices (the blocked sweep's order) over a table of 1M elements.
+//   hipcc -O3 --offload-arch=gfx950 -o /tmp/gcp gather_cache_policy.hip && /tmp/gcp
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
-#include <vector>
 #include <random>
-#define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("%s: %s\n",#x,hipGetErrorString(e)); exit(1);} }while(0)
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-template<int POLICY> __device__ __forceinline__ void gload(double& v, const double* p) {
-  if (POLICY==0) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p));
-  if (POLICY==1) asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(v) : "v"(p));
-  if (POLICY==2) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p));
-  if (POLICY==3) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p));
-  if (POLICY==4) asm volatile("global_load_dwordx2 %0, %1, off sc0" : "=v"(v) : "v"(p));
+static const int BLOCKS = 256, THREADS = 1024, PER_BLOCK = 65536, U = 4;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define KERNEL32(NAME, BITS)                                                                                         \
+    __global__ __launch_bounds__(1024) void NAME(const char* __restrict__ tab, const uint32_t* __restrict__ idx, uint32_t* out) { \
+        const uint32_t* my = idx + (size_t)blockIdx.x * PER_BLOCK;                                                   \
+        uint32_t acc = 0;                                                                                            \
+        for (int e = threadIdx.x; e < PER_BLOCK; e += U * 1024) {                                                    \
+            uint32_t c[U];                                                                                           \
+            u32x4 lo[U], hi[U];                                                                                      \
+            _Pragma("unroll") for (int u = 0; u < U; ++u) c[u] = my[e + u * 1024];                                   \
+            _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                          \
+                const char* p = tab + (size_t)c[u] * 32;                                                             \
+                asm volatile("global_load_dwordx4 %0, %1, off " BITS : "=v"(lo[u]) : "v"(p) : "memory");            \
+                asm volatile("global_load_dwordx4 %0, %1, off offset:16 " BITS : "=v"(hi[u]) : "v"(p) : "memory");  \
+            }                                                                                                        \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
+            _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                          \
+                asm volatile("" : "+v"(lo[u]), "+v"(hi[u]));                                                         \
+                acc ^= lo[u].x ^ lo[u].w ^ hi[u].y ^ hi[u].z;                                                        \
+            }                                                                                                        \
+        }                                                                                                            \
+        if (acc == 0x12345678u) out[0] = acc;                                                                        \
+    }
+#define KERNEL8(NAME, BITS)                                                                                          \
+    __global__ __launch_bounds__(1024) void NAME(const char* __restrict__ tab, const uint32_t* __restrict__ idx, uint32_t* out) { \
+        const uint32_t* my = idx + (size_t)blockIdx.x * PER_BLOCK;                                                   \
+        uint32_t acc = 0;                                                                                            \
+        for (int e = threadIdx.x; e < PER_BLOCK; e += U * 1024) {                                                    \
+            uint32_t c[U];                                                                                           \
+            u32x2 v[U];                                                                                              \
+            _Pragma("unroll") for (int u = 0; u < U; ++u) c[u] = my[e + u * 1024];                                   \
+            _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                          \
+                const char* p = tab + (size_t)c[u] * 8;                                                              \
+                asm volatile("global_load_dwordx2 %0, %1, off " BITS : "=v"(v[u]) : "v"(p) : "memory");             \
+            }                                                                                                        \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
+            _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                          \
+                asm volatile("" : "+v"(v[u]));                                                                       \
+                acc ^= v[u].x ^ v[u].y;                                                                              \
+            }                                                                                                        \
+        }                                                                                                            \
+        if (acc == 0x12345678u) out[0] = acc;                                                                        \
+    }
+
+KERNEL32(k32_plain, "")
+KERNEL32(k32_nt, "nt")
+KERNEL32(k32_sc0, "sc0")
+KERNEL32(k32_sc1, "sc1")
+KERNEL32(k32_sc0_sc1, "sc0 sc1")
+KERNEL32(k32_sc0_nt, "sc0 nt")
+KERNEL32(k32_sc1_nt, "sc1 nt")
+KERNEL32(k32_all, "sc0 sc1 nt")
+KERNEL8(k8_plain, "")
+KERNEL8(k8_nt, "nt")
+KERNEL8(k8_sc0, "sc0")
+KERNEL8(k8_sc1, "sc1")
+KERNEL8(k8_sc0_sc1, "sc0 sc1")
+KERNEL8(k8_sc0_nt, "sc0 nt")
+KERNEL8(k8_sc1_nt, "sc1 nt")
+KERNEL8(k8_all, "sc0 sc1 nt")
+
+typedef void (*Kern)(const char*, const uint32_t*, uint32_t*);
+
+static float time_it(Kern k, const char* tab, const uint32_t* idx, uint32_t* out) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(BLOCKS), dim3(THREADS), 0, 0, tab, idx, out);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k, dim3(BLOCKS), dim3(THREADS), 0, 0, tab, idx, out);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / 20 * 1000.f;
 }
-template<int U, int POLICY>
-__global__ __launch_bounds__(256) void k_gather(const uint32_t* __restrict__ col, const double* __restrict__ x, double* out, size_t n) {
-  size_t tid = (size_t)blockIdx.x*256+threadIdx.x, stride=(size_t)gridDim.x*256;
-  double acc=0;
-  for (size_t i=tid; i+ (U-1)*stride < n; i+=U*stride) {
-    uint32_t c[U]; double xv[U];
-#pragma unroll
-    for(int u=0;u<U;++u) c[u]=col[i+u*stride];
-#pragma unroll
-    for(int u=0;u<U;++u) gload<POLICY>(xv[u], x + c[u]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for(int u=0;u<U;++u) acc+= xv[u];
-  }
-  if (acc==12345.678) out[tid]=acc;
-}
-template<typename F> float timeit(F f, int reps=20){
-  hipEvent_t a,b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  for(int i=0;i<3;++i) f();
-  CK(hipEventRecord(a)); for(int i=0;i<reps;++i) f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
-  float ms; CK(hipEventElapsedTime(&ms,a,b)); return ms/reps*1000.f;
-}
-int main(){
-  size_t n = 16777216;
-  std::vector<uint32_t> h(n);
-  uint32_t* col; double* x; double* out;
-  size_t TMAX = 1u<<24;
-  CK(hipMalloc(&col,n*4)); CK(hipMalloc(&x,TMAX*8)); CK(hipMalloc(&out,(size_t)4096*1024*8));
-  CK(hipMemset(x,0,TMAX*8));
-  std::mt19937_64 rng(1);
-  for (size_t T : {size_t(1)<<10, size_t(1)<<11, size_t(1)<<12, size_t(1)<<14, size_t(1)<<17, size_t(1)<<19, size_t(1)<<20, size_t(1)<<22}) {
-    for (auto& v: h) v = rng()%T;
-    CK(hipMemcpy(col,h.data(),n*4,hipMemcpyHostToDevice));
-    float a = timeit([&]{ hipLaunchKernelGGL((k_gather<8,0>),dim3(2048),dim3(256),0,0,col,x,out,n); });
-    float b = timeit([&]{ hipLaunchKernelGGL((k_gather<8,1>),dim3(2048),dim3(256),0,0,col,x,out,n); });
-    float c = timeit([&]{ hipLaunchKernelGGL((k_gather<8,2>),dim3(2048),dim3(256),0,0,col,x,out,n); });
-    float d = timeit([&]{ hipLaunchKernelGGL((k_gather<8,3>),dim3(2048),dim3(256),0,0,col,x,out,n); });
-    float e = timeit([&]{ hipLaunchKernelGGL((k_gather<8,4>),dim3(2048),dim3(256),0,0,col,x,out,n); });
-    float f = timeit([&]{ hipLaunchKernelGGL((k_gather<16,0>),dim3(2048),dim3(256),0,0,col,x,out,n); });
-    float g = timeit([&]{ hipLaunchKernelGGL((k_gather<16,2>),dim3(2048),dim3(256),0,0,col,x,out,n); });
-    printf("unif T=%8zu (%7.3f MB): plain %.1f | nt %.1f | sc1 %.1f | sc0sc1 %.1f | sc0 %.1f | plain U16 %.1f | sc1 U16 %.1f us\n", T, T*8/1048576.0, a,b,c,d,e,f,g);
-  }
-  return 0;
+
+int main(int argc, char** argv) {
+    const int only = argc > 1 ? atoi(argv[1]) : -1;       // run one variant only (for a counter pass)
+    uint32_t* d_out; CK(hipMalloc(&d_out, 64));
+    const size_t entries = size_t(1) << 20;
+    std::mt19937_64 rng(7);
+    std::vector<uint32_t> idx((size_t)BLOCKS * PER_BLOCK);
+    for (int b = 0; b < BLOCKS; ++b) {
+        uint32_t* p = idx.data() + (size_t)b * PER_BLOCK;
+        for (int i = 0; i < PER_BLOCK; ++i) p[i] = (uint32_t)(rng() % entries);
+        std::sort(p, p + PER_BLOCK);
+    }
+    uint32_t* d_idx; char* d_tab;
+    CK(hipMalloc(&d_idx, idx.size() * 4)); CK(hipMemcpy(d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_tab, entries * 32)); CK(hipMemset(d_tab, 1, entries * 32));
+    struct V { const char* name; Kern k32, k8; } vs[] = {
+        {"plain", k32_plain, k8_plain}, {"nt", k32_nt, k8_nt}, {"sc0", k32_sc0, k8_sc0}, {"sc1", k32_sc1, k8_sc1},
+        {"sc0 sc1", k32_sc0_sc1, k8_sc0_sc1}, {"sc0 nt", k32_sc0_nt, k8_sc0_nt}, {"sc1 nt", k32_sc1_nt, k8_sc1_nt},
+        {"sc0 sc1 nt", k32_all, k8_all}};
+    int i = 0;
+    for (const V& v : vs) {
+        if (only >= 0 && only != i++) continue;
+        float t32 = time_it(v.k32, d_tab, d_idx, d_out);
+        float t8 = time_it(v.k8, d_tab, d_idx, d_out);
+        printf("%-12s : 32-byte gathers %6.1f us | 8-byte gathers %6.1f us   (16.8M gathers, 1M-element table)\n", v.name, t32, t8);
+    }
+    return 0;
 }
