@@ -378,7 +378,6 @@ struct RecordWalk {
     RecordWalk(const Geometry& geo_, unsigned T_, const std::vector<uint32_t>& src_in, const std::vector<uint32_t>& row_in,
                const std::vector<uint32_t>& val_in) : geo(geo_), T(T_), count(src_in.size()) {
         // sort by visit key: T buckets of equal key ranges (sources are spread evenly over the positions), each sorted by its owner
-        const uint64_t key_end = ((uint64_t)geo.n_chunks << 32);
         auto key_of = [&](uint32_t code) -> uint64_t {
             const uint32_t local = code & COL_LOCAL_MASK;
             return ((uint64_t)(geo.n_chunks > 1 ? geo.chunk_of_local(local) : 0u) << 32) | geo.pos_of_col(code);
@@ -389,7 +388,6 @@ struct RecordWalk {
             const long double frac = ((long double)(key >> 32) + (long double)(key & 0xFFFFFFFFull) / (long double)vec_len) / (long double)geo.n_chunks;
             return (unsigned)std::min<long double>(T - 1, frac * T);
         };
-        (void)key_end;
         std::vector<uint64_t> cnt((size_t)T * T, 0);
         run_threads(T, [&](unsigned t) {
             for (uint64_t k = count * t / T; k < count * (t + 1) / T; ++k) ++cnt[(size_t)t * T + bucket_of(key_of(src_in[k]))];

@@ -173,8 +173,11 @@ struct StepArgsF64B {
     uint32_t phase, n_phases;
 };
 
-template <typename VT, bool HAS_ALPHA, bool PACKED = false>
+// PHASED: one of several launches of an iteration (chunked exchange); otherwise the launch is the whole iteration and
+// none of the phase bookkeeping is compiled in.
+template <typename VT, bool HAS_ALPHA, bool PACKED = false, bool PHASED = false>
 __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
+    static_assert(!(PACKED && PHASED), "runs of a chunked list do not start on a 64-edge boundary");
     constexpr bool RAW = sizeof(VT) != sizeof(double);
     static_assert(!PACKED || sizeof(VT) == 1, "packed records carry byte opinions");
     extern __shared__ double acc_l[];
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     const size_t my_base = (size_t)a.geo.seg * stride;
     const double* __restrict__ xr = a.x;
     const VT* __restrict__ wr = static_cast<const VT*>(a.w);
-    const bool first_phase = a.phase == 0, last_phase = a.phase + 1 == a.n_phases;
+    const bool first_phase = !PHASED || a.phase == 0, last_phase = !PHASED || a.phase + 1 == a.n_phases;
     for (uint32_t i = threadIdx.x; i < RB; i += 1024) acc_l[i] = first_phase ? 0.0 : a.acc_g[(size_t)b * RB + i];
     // the step owns the whole partial-sum tail of its segment of y: slots no workgroup writes are set to zero, so the
     // next step's sum over all nd_cap slots never reads what the caller's allocation happened to hold
@@ -229,8 +232,8 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     }
     __syncthreads();
 
-    const uint64_t e0 = a.n_phases > 1 ? a.phase_ptr[(size_t)b * (a.n_phases + 1) + a.phase] : a.bk_ptr[b];
-    const uint64_t e1 = a.n_phases > 1 ? a.phase_ptr[(size_t)b * (a.n_phases + 1) + a.phase + 1] : a.bk_ptr[b + 1];
+    const uint64_t e0 = PHASED ? a.phase_ptr[(size_t)b * (a.n_phases + 1) + a.phase] : a.bk_ptr[b];
+    const uint64_t e1 = PHASED ? a.phase_ptr[(size_t)b * (a.n_phases + 1) + a.phase + 1] : a.bk_ptr[b + 1];
     constexpr int U = 4;
     // Full batches of U * 1024 edges, the same number for every thread.  The hardware favours the
     // oldest wavefront of a workgroup, which lets it run far ahead of the youngest; a barrier every
@@ -736,7 +739,8 @@ __global__ void k_scale_288(const uint4* __restrict__ scale576, uint4* __restric
 // on).  Each wrap is compensated exactly once, every addend is non-negative and the final sum is below 2^288, so once
 // all adds have landed the limbs hold the exact integer whatever the order.
 // !COMPACT: eight 64-bit column sums per row [8][RB] (limb times opinion byte, no carries until the row is folded).
-template <bool COMPACT>
+// PHASED: as for the f64 sweep.
+template <bool COMPACT, bool PHASED = false>
 __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     extern __shared__ unsigned long long colsum_l[];
     __shared__ uint32_t sh_d[9];
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     const uint32_t stride = a.geo.seg_stride();
     const size_t my_base = (size_t)a.geo.seg * stride;
     uint32_t* const top_l = reinterpret_cast<uint32_t*>(colsum_l + 4 * (size_t)RB);   // COMPACT: limb 8 of every row
-    const bool first_phase = a.phase == 0, last_phase = a.phase + 1 == a.n_phases;
+    const bool first_phase = !PHASED || a.phase == 0, last_phase = !PHASED || a.phase + 1 == a.n_phases;
     const uint32_t lds_words = COMPACT ? 4 * RB + RB / 2 : 8 * RB;                     // RB is a multiple of 16
     for (uint32_t i = threadIdx.x; i < lds_words; i += 1024) colsum_l[i] = first_phase ? 0ull : a.acc_g[(size_t)b * lds_words + i];
     // partial-sum slots no workgroup writes: zero, whatever the caller's buffer held (see fr_zero_unused_tail)
@@ -771,11 +775,17 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
         }
     }
 
-    const uint64_t e0 = a.n_phases > 1 ? a.phase_ptr[(size_t)b * (a.n_phases + 1) + a.phase] : a.ptr[b];
-    const uint64_t e1 = a.n_phases > 1 ? a.phase_ptr[(size_t)b * (a.n_phases + 1) + a.phase + 1] : a.ptr[b + 1];
-    // three edges per thread in flight and a barrier every second batch: 145 us on the 1M-peer benchmark graph against
-    // 153 us for four (150 us for two, 156 us without the barriers' help or with a barrier every batch)
-    constexpr int U = 3;
+    const uint64_t e0 = PHASED ? a.phase_ptr[(size_t)b * (a.n_phases + 1) + a.phase] : a.ptr[b];
+    const uint64_t e1 = PHASED ? a.phase_ptr[(size_t)b * (a.n_phases + 1) + a.phase + 1] : a.ptr[b + 1];
+    // ONE edge per thread in flight and a barrier every eighth pass.  The two 16-byte halves of a gathered element share a
+    // cache line: with one element per thread the second half's request meets the line the first half's miss is already
+    // bringing; with more elements in flight per thread (16 wavefronts x 64 lanes x U lines against a 256-line L1) the line
+    // is often gone again and fetched twice.  1M-peer benchmark graph: U = 1 / 2 / 3 / 4 at their best barrier periods
+    // 112 / 119 / 119 / 121 us; U = 1 with a barrier every 4 / 8 / 16 / 32 passes 112.7 / 112.3 / 115.0 / 117.4, none 126.
+    // Asking for the next element's halves before this element's adds (two in flight again) costs 6 us, non-temporal
+    // record loads 17 us.
+    constexpr int U = 1;
+    constexpr int BAR = 8;
     const uint32_t n_batches = (uint32_t)((e1 - e0) / (U * 1024));
     uint64_t e = e0 + threadIdx.x;
     // a carry into word k of a row (k = 1..3), or into the top limb (k = 4)
@@ -845,7 +855,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             for (int u = 0; u < U; ++u) { cn[u] = a.col[en + u * 1024]; vn[u] = a.val[en + u * 1024]; rn[u] = a.row[en + u * 1024]; }
 #pragma unroll
             for (int u = 0; u < U; ++u) add_edge(r[u], v[u], lo[u], hi[u]);
-            if (k & 1) __syncthreads();
+            if (k % BAR == BAR - 1) __syncthreads();
 #pragma unroll
             for (int u = 0; u < U; ++u) { c[u] = cn[u]; v[u] = vn[u]; r[u] = rn[u]; }
         }
@@ -1228,8 +1238,9 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
             if ((rc = dev_upload(&g->d_fb_ptr, h.fb_ptr, tot)) || (rc = dev_upload(&g->d_fb_grp, h.fb_grp, tot)) ||
                 (rc = dev_upload(&g->d_fb_col, h.fb_col, tot)) || (rc = dev_upload(&g->d_fb_row, h.fb_row, tot)) ||
                 (rc = dev_upload(&g->d_fb_val, h.fb_val, tot))) return rc;
-            HIP_TRY(hipFuncSetAttribute((const void*)k_step_fr_blocked<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_step_fr_blocked<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            const void* sweeps[] = {(const void*)k_step_fr_blocked<true, false>, (const void*)k_step_fr_blocked<false, false>,
+                                    (const void*)k_step_fr_blocked<true, true>, (const void*)k_step_fr_blocked<false, true>};
+            for (const void* f : sweeps) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
             // the sweep multiplies unreduced row sums by inv(sum) * 2^288 (the resident factors carry 2^576)
             if ((rc = dev_alloc(&g->d_fb_scale, vec_len * 2, tot))) return rc;
             hipLaunchKernelGGL(k_scale_288, dim3((unsigned)((vec_len + 255) / 256)), dim3(256), 0, 0, g->d_scale_fr, g->d_fb_scale, vec_len);
@@ -1243,6 +1254,7 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     {
         const int lds_max = 160 * 1024 - 1024;
         const void* fns[] = {(const void*)k_step_f64_blocked<uint8_t, false, true>, (const void*)k_step_f64_blocked<uint8_t, true, true>,
+                             (const void*)k_step_f64_blocked<uint8_t, false, false, true>, (const void*)k_step_f64_blocked<uint8_t, true, false, true>,
                              (const void*)k_step_f64_blocked<uint8_t, false>, (const void*)k_step_f64_blocked<uint8_t, true>,
                              (const void*)k_step_f64_blocked<uint32_t, false>, (const void*)k_step_f64_blocked<uint32_t, true>,
                              (const void*)k_step_f64_blocked<double, false>, (const void*)k_step_f64_blocked<double, true>};
@@ -1274,10 +1286,10 @@ int DeviceGraph::init_fr(uint64_t lo, uint64_t hi, uint4* x, hipStream_t st, boo
     HIP_TRY(hipGetLastError());
     return ET_OK;
 }
-template <typename VT, bool PACKED = false>
+template <typename VT, bool PACKED = false, bool PHASED = false>
 static void launch_f64(const StepArgsF64B& a, unsigned blocks, size_t lds, hipStream_t st) {
-    if (a.alpha != 0.0) hipLaunchKernelGGL((k_step_f64_blocked<VT, true, PACKED>), dim3(blocks), dim3(1024), lds, st, a);
-    else hipLaunchKernelGGL((k_step_f64_blocked<VT, false, PACKED>), dim3(blocks), dim3(1024), lds, st, a);
+    if (a.alpha != 0.0) hipLaunchKernelGGL((k_step_f64_blocked<VT, true, PACKED, PHASED>), dim3(blocks), dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((k_step_f64_blocked<VT, false, PACKED, PHASED>), dim3(blocks), dim3(1024), lds, st, a);
 }
 int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, uint32_t flags, hipStream_t st, int phase) {
     if (!(variants & ET_VARIANT_F64)) { set_error("graph was built without the f64 variant"); return ET_E_UNSUPPORTED; }
@@ -1296,7 +1308,11 @@ int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double
     // phase < 0: the whole iteration, as n_chunks launches one after the other
     for (uint32_t q = phase < 0 ? 0u : (uint32_t)phase; q < (phase < 0 ? geo.n_chunks : (uint32_t)phase + 1); ++q) {
         a.phase = q;
-        if (!raw) launch_f64<double>(a, geo.f64_blocks, lds, st);
+        if (geo.n_chunks > 1) {   // several launches per iteration: byte opinions, unpacked records (see create)
+            if (!raw || val_bytes != 1 || packed) { set_error("internal: chunked graph without byte records"); return ET_E_UNSUPPORTED; }
+            launch_f64<uint8_t, false, true>(a, geo.f64_blocks, lds, st);
+        }
+        else if (!raw) launch_f64<double>(a, geo.f64_blocks, lds, st);
         else if (packed) launch_f64<uint8_t, true>(a, geo.f64_blocks, lds, st);
         else if (val_bytes == 1) launch_f64<uint8_t>(a, geo.f64_blocks, lds, st);
         else launch_f64<uint32_t>(a, geo.f64_blocks, lds, st);
@@ -1318,8 +1334,15 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
         if (phase >= (int)geo.n_chunks) { set_error("no such phase"); return ET_E_OUT_OF_RANGE; }
         for (uint32_t q = phase < 0 ? 0u : (uint32_t)phase; q < (phase < 0 ? geo.n_chunks : (uint32_t)phase + 1); ++q) {
             fb.phase = q;
-            if (geo.fr_compact) hipLaunchKernelGGL(k_step_fr_blocked<true>, dim3(geo.fr_blocks), dim3(1024), (size_t)geo.fr_rb * 36, st, fb);
-            else hipLaunchKernelGGL(k_step_fr_blocked<false>, dim3(geo.fr_blocks), dim3(1024), (size_t)geo.fr_rb * 64, st, fb);
+            const dim3 grid(geo.fr_blocks), wg(1024);
+            const size_t lds = (size_t)geo.fr_rb * (geo.fr_compact ? 36 : 64);
+            if (geo.n_chunks > 1) {
+                if (geo.fr_compact) hipLaunchKernelGGL((k_step_fr_blocked<true, true>), grid, wg, lds, st, fb);
+                else hipLaunchKernelGGL((k_step_fr_blocked<false, true>), grid, wg, lds, st, fb);
+            } else {
+                if (geo.fr_compact) hipLaunchKernelGGL((k_step_fr_blocked<true, false>), grid, wg, lds, st, fb);
+                else hipLaunchKernelGGL((k_step_fr_blocked<false, false>), grid, wg, lds, st, fb);
+            }
         }
         HIP_TRY(hipGetLastError());
         return ET_OK;
