@@ -705,6 +705,10 @@ struct StepArgsFrB {
     const uint32_t* col;
     const uint16_t* row;
     const uint8_t* val;
+    // packed records (see k_step_f64_blocked): accumulator row | (source position - base of the 64-edge chunk) << 16
+    const uint32_t* rec;
+    const uint32_t* cbase;
+    const uint64_t* cptr;
     const uint4* x;
     uint4* y;
     uint4* own;
@@ -740,8 +744,10 @@ __global__ void k_scale_288(const uint4* __restrict__ scale576, uint4* __restric
 // all adds have landed the limbs hold the exact integer whatever the order.
 // !COMPACT: eight 64-bit column sums per row [8][RB] (limb times opinion byte, no carries until the row is folded).
 // PHASED: as for the f64 sweep.
-template <bool COMPACT, bool PHASED = false>
+// PACKED: 5-byte edge records (one 32-bit record and the opinion byte) in place of 7 bytes (source, row, opinion).
+template <bool COMPACT, bool PHASED = false, bool PACKED = false>
 __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
+    static_assert(!(PACKED && PHASED), "runs of a chunked list do not start on a 64-edge boundary");
     extern __shared__ unsigned long long colsum_l[];
     __shared__ uint32_t sh_d[9];
     __shared__ uint32_t sh_pd[17];
@@ -836,23 +842,39 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     {
         // the records of batch k+1 are asked for before the gathers of batch k are used: a record comes from memory
         // and the gather's address from the record, so the two trips of a batch would otherwise follow each other
+        // c: the source's position in the vector (PACKED) or its (segment, local row) code; r: the accumulator row
         uint32_t c[U], v[U], r[U];
+        const uint32_t* __restrict__ cb = PACKED ? a.cbase + a.cptr[b] : nullptr;
+        auto fetch = [&](uint64_t i, uint32_t& cc, uint32_t& vv, uint32_t& rr) {
+            vv = a.val[i];
+            if (PACKED) {
+                const uint32_t rc = a.rec[i];
+                cc = cb[(i - e0) >> 6] + (rc >> 16);
+                rr = rc & 0xFFFFu;
+            } else {
+                cc = a.col[i];
+                rr = a.row[i];
+            }
+        };
+        auto entry = [&](uint32_t cc) -> const uint4* {
+            return a.x + 2 * (PACKED ? (size_t)cc : (size_t)(cc >> COL_SEG_SHIFT) * stride + (cc & COL_LOCAL_MASK));
+        };
         if (n_batches) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) { c[u] = a.col[e + u * 1024]; v[u] = a.val[e + u * 1024]; r[u] = a.row[e + u * 1024]; }
+            for (int u = 0; u < U; ++u) fetch(e + u * 1024, c[u], v[u], r[u]);
         }
         for (uint32_t k = 0; k < n_batches; ++k, e += U * 1024) {
             uint4 lo[U], hi[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const uint4* p = a.x + 2 * ((size_t)(c[u] >> COL_SEG_SHIFT) * stride + (c[u] & COL_LOCAL_MASK));
+                const uint4* p = entry(c[u]);
                 lo[u] = p[0];
                 hi[u] = p[1];
             }
             uint32_t cn[U], vn[U], rn[U];
             const uint64_t en = k + 1 < n_batches ? e + U * 1024 : e;      // the last pass reads its own records again
 #pragma unroll
-            for (int u = 0; u < U; ++u) { cn[u] = a.col[en + u * 1024]; vn[u] = a.val[en + u * 1024]; rn[u] = a.row[en + u * 1024]; }
+            for (int u = 0; u < U; ++u) fetch(en + u * 1024, cn[u], vn[u], rn[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) add_edge(r[u], v[u], lo[u], hi[u]);
             if (k % BAR == BAR - 1) __syncthreads();
@@ -867,13 +889,22 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
         for (int u = 0; u < U; ++u) {
             const uint64_t i = e + u * 1024;
             const bool in = i < e1;
-            c[u] = in ? a.col[i] : 0u;
-            v[u] = in ? a.val[i] : 0u;
-            r[u] = in ? a.row[i] : 0u;
+            c[u] = v[u] = r[u] = 0u;                        // position / code 0 is a valid address
+            if (in) {
+                v[u] = a.val[i];
+                if (PACKED) {
+                    const uint32_t rc = a.rec[i];
+                    c[u] = a.cbase[a.cptr[b] + ((i - e0) >> 6)] + (rc >> 16);
+                    r[u] = rc & 0xFFFFu;
+                } else {
+                    c[u] = a.col[i];
+                    r[u] = a.row[i];
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint4* p = a.x + 2 * ((size_t)(c[u] >> COL_SEG_SHIFT) * stride + (c[u] & COL_LOCAL_MASK));
+            const uint4* p = a.x + 2 * (PACKED ? (size_t)c[u] : (size_t)(c[u] >> COL_SEG_SHIFT) * stride + (c[u] & COL_LOCAL_MASK));
             lo[u] = p[0];
             hi[u] = p[1];
         }
@@ -1088,7 +1119,7 @@ static int dev_upload(T** p, const std::vector<T>& v, uint64_t& total) {
 
 DeviceGraph::~DeviceGraph() {
     if (device >= 0) (void)hipSetDevice(device);
-    void* ptrs[] = {d_bk_ptr, d_bk_grp, d_bk_col, d_bk_row, d_bk_w, d_bk_rec, d_bk_cbase, d_bk_cptr, d_fb_ptr, d_fb_grp, d_fb_col, d_fb_row, d_fb_val, d_work, d_slices, d_col, d_val, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
+    void* ptrs[] = {d_fb_rec, d_fb_cbase, d_fb_cptr, d_bk_ptr, d_bk_grp, d_bk_col, d_bk_row, d_bk_w, d_bk_rec, d_bk_cbase, d_bk_cptr, d_fb_ptr, d_fb_grp, d_fb_col, d_fb_row, d_fb_val, d_work, d_slices, d_col, d_val, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
                     d_chg_part, d_stat_out, d_bk_phase, d_fb_phase, d_f64_acc, d_fr_acc, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust, d_scale64, d_scale_fr, d_fb_scale, own64, own_fr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* e : ev_begin) (void)hipEventDestroy((hipEvent_t)e);
@@ -1099,6 +1130,33 @@ static U256 to_u256(const FrRaw& r) {
     U256 u;
     for (int i = 0; i < 4; ++i) { u.v[2 * i] = (uint32_t)r.l[i]; u.v[2 * i + 1] = (uint32_t)(r.l[i] >> 32); }
     return u;
+}
+
+// Packs a blocked sweep's (source, row) pairs into one 32-bit record each: row | (position - base) << 16, with one base
+// position per 64 consecutive edges of a workgroup's list (the lists ascend by position).  False when some chunk spans
+// more than 65535 positions.
+static bool pack_records(const Geometry& geo, uint32_t B, const std::vector<uint64_t>& ptr, const std::vector<uint32_t>& col,
+                         const std::vector<uint16_t>& row, std::vector<uint64_t>& cptr, std::vector<uint32_t>& cbase,
+                         std::vector<uint32_t>& rec) {
+    cptr.assign((size_t)B + 1, 0);
+    for (uint32_t b = 0; b < B; ++b) cptr[b + 1] = cptr[b] + (ptr[b + 1] - ptr[b] + 63) / 64;
+    cbase.assign(cptr[B], 0);
+    rec.assign(col.size(), 0);
+    std::atomic<bool> fits(true);
+    const unsigned T = host_threads();
+    run_threads(T, [&](unsigned t) {
+        for (uint32_t b = (uint32_t)((uint64_t)B * t / T); b < (uint32_t)((uint64_t)B * (t + 1) / T); ++b) {
+            uint32_t base = 0;
+            for (uint64_t q = ptr[b]; q < ptr[b + 1]; ++q) {
+                const uint32_t pos = geo.pos_of_col(col[q]);
+                const uint64_t rel = q - ptr[b];
+                if ((rel & 63) == 0) { base = pos; cbase[cptr[b] + rel / 64] = base; }
+                if (pos - base > 0xFFFFu) fits = false;
+                rec[q] = (uint32_t)row[q] | ((pos - base) << 16);
+            }
+        }
+    });
+    return fits;
 }
 
 int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGraph** out) {
@@ -1153,6 +1211,7 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     if ((rc = dev_alloc(&g->d_scale_fr, vec_len * 2, tot))) return rc;
     HIP_TRY(hipMemcpy(g->d_scale_fr, h.scale_fr.data(), vec_len * 32, hipMemcpyHostToDevice));
     const unsigned nb = (unsigned)((slots + 255) / 256);
+    const bool can_pack = g->raw && g->val_bytes == 1 && vec_len <= 0xFFFFFFFFull && h.geo.n_chunks == 1;
     if (g->variants & ET_VARIANT_F64) {
         g->n_f64_parts = h.geo.f64_blocks;
         const size_t ne = h.bk_col.size();
@@ -1160,26 +1219,10 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
         // byte opinions: 5-byte edge records (see k_step_f64_blocked) unless a chunk of 64 consecutive edges of a
         // workgroup spans more than 65535 positions (a few edges over very many peers) or positions need 33 bits
         // (a chunked exchange cuts a list into runs that do not start on a 64-edge boundary: 7-byte records there)
-        if (g->raw && g->val_bytes == 1 && vec_len <= 0xFFFFFFFFull && h.geo.n_chunks == 1 && !getenv("ET_F64_UNPACKED")) {
-            const uint32_t B = h.geo.f64_blocks;
-            std::vector<uint64_t> cptr((size_t)B + 1, 0);
-            for (uint32_t b = 0; b < B; ++b) cptr[b + 1] = cptr[b] + (h.bk_ptr[b + 1] - h.bk_ptr[b] + 63) / 64;
-            std::vector<uint32_t> cbase(cptr[B]), rec(ne);
-            std::atomic<bool> fits(true);
-            run_threads(host_threads(), [&](unsigned t) {
-                const unsigned T = host_threads();
-                for (uint32_t b = (uint32_t)((uint64_t)B * t / T); b < (uint32_t)((uint64_t)B * (t + 1) / T); ++b) {
-                    uint32_t base = 0;
-                    for (uint64_t q = h.bk_ptr[b]; q < h.bk_ptr[b + 1]; ++q) {
-                        const uint32_t pos = h.geo.pos_of_col(h.bk_col[q]);
-                        const uint64_t rel = q - h.bk_ptr[b];
-                        if ((rel & 63) == 0) { base = pos; cbase[cptr[b] + rel / 64] = base; }
-                        if (pos - base > 0xFFFFu) fits = false;
-                        rec[q] = (uint32_t)h.bk_row[q] | ((pos - base) << 16);
-                    }
-                }
-            });
-            if (fits) {
+        if (can_pack && !getenv("ET_F64_UNPACKED")) {
+            std::vector<uint64_t> cptr;
+            std::vector<uint32_t> cbase, rec;
+            if (pack_records(h.geo, h.geo.f64_blocks, h.bk_ptr, h.bk_col, h.bk_row, cptr, cbase, rec)) {
                 g->packed = true;
                 if ((rc = dev_upload(&g->d_bk_rec, rec, tot)) || (rc = dev_upload(&g->d_bk_cbase, cbase, tot)) ||
                     (rc = dev_upload(&g->d_bk_cptr, cptr, tot))) return rc;
@@ -1236,9 +1279,19 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
         }
         if (g->fr_blocked) {
             if ((rc = dev_upload(&g->d_fb_ptr, h.fb_ptr, tot)) || (rc = dev_upload(&g->d_fb_grp, h.fb_grp, tot)) ||
-                (rc = dev_upload(&g->d_fb_col, h.fb_col, tot)) || (rc = dev_upload(&g->d_fb_row, h.fb_row, tot)) ||
                 (rc = dev_upload(&g->d_fb_val, h.fb_val, tot))) return rc;
-            const void* sweeps[] = {(const void*)k_step_fr_blocked<true, false>, (const void*)k_step_fr_blocked<false, false>,
+            if (can_pack && h.geo.fr_compact && !getenv("ET_FR_UNPACKED")) {
+                std::vector<uint64_t> cptr;
+                std::vector<uint32_t> cbase, rec;
+                if (pack_records(h.geo, h.geo.fr_blocks, h.fb_ptr, h.fb_col, h.fb_row, cptr, cbase, rec)) {
+                    g->fr_packed = true;
+                    if ((rc = dev_upload(&g->d_fb_rec, rec, tot)) || (rc = dev_upload(&g->d_fb_cbase, cbase, tot)) ||
+                        (rc = dev_upload(&g->d_fb_cptr, cptr, tot))) return rc;
+                }
+            }
+            if (!g->fr_packed && ((rc = dev_upload(&g->d_fb_col, h.fb_col, tot)) || (rc = dev_upload(&g->d_fb_row, h.fb_row, tot)))) return rc;
+            const void* sweeps[] = {(const void*)k_step_fr_blocked<true, false, true>,
+                                    (const void*)k_step_fr_blocked<true, false>, (const void*)k_step_fr_blocked<false, false>,
                                     (const void*)k_step_fr_blocked<true, true>, (const void*)k_step_fr_blocked<false, true>};
             for (const void* f : sweeps) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
             // the sweep multiplies unreduced row sums by inv(sum) * 2^288 (the resident factors carry 2^576)
@@ -1327,6 +1380,7 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
         StepArgsFrB fb;
         const size_t ringb = (size_t)(iteration % STATS_RING) * n_fr_parts;
         fb.ptr = d_fb_ptr; fb.grp = d_fb_grp; fb.col = d_fb_col; fb.row = d_fb_row; fb.val = d_fb_val; fb.x = x; fb.y = y;
+        fb.rec = d_fb_rec; fb.cbase = d_fb_cbase; fb.cptr = d_fb_cptr;
         fb.own = own_fr; fb.scale288 = d_fb_scale; fb.sum_part = d_frsum_part + 2 * ringb; fb.chg_part = d_chg_part + ringb;
         fb.geo = geo; fb.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u; fb.inv_nm1_w = to_u256(inv_nm1_w);
         fb.inv_nm1_w576 = to_u256((Fr::from_raw(inv_nm1_w) * Fr::one().pow2k(288)).to_raw());
@@ -1340,7 +1394,8 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
                 if (geo.fr_compact) hipLaunchKernelGGL((k_step_fr_blocked<true, true>), grid, wg, lds, st, fb);
                 else hipLaunchKernelGGL((k_step_fr_blocked<false, true>), grid, wg, lds, st, fb);
             } else {
-                if (geo.fr_compact) hipLaunchKernelGGL((k_step_fr_blocked<true, false>), grid, wg, lds, st, fb);
+                if (fr_packed) hipLaunchKernelGGL((k_step_fr_blocked<true, false, true>), grid, wg, lds, st, fb);
+                else if (geo.fr_compact) hipLaunchKernelGGL((k_step_fr_blocked<true, false>), grid, wg, lds, st, fb);
                 else hipLaunchKernelGGL((k_step_fr_blocked<false, false>), grid, wg, lds, st, fb);
             }
         }

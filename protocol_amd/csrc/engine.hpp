@@ -55,6 +55,11 @@ struct DeviceGraph {
     uint32_t* d_bk_rec = nullptr;
     uint32_t* d_bk_cbase = nullptr;
     uint64_t* d_bk_cptr = nullptr;
+    // the same packing for the exact blocked sweep's lists
+    bool fr_packed = false;
+    uint32_t* d_fb_rec = nullptr;
+    uint32_t* d_fb_cbase = nullptr;
+    uint64_t* d_fb_cptr = nullptr;
     // exact blocked sweep (geo.fr_blocks != 0): per-workgroup edge lists like the f64 ones
     bool fr_blocked = false;
     uint32_t n_fr_parts = 0;          // partial statistics per launch: workgroups of the blocked sweep, else wavefront work items

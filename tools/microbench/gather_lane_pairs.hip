@@ -89,6 +89,13 @@ int main() {
             uint32_t* d_idx; uint4* d_tab;
             CK(hipMalloc(&d_idx, idx.size() * 4)); CK(hipMemcpy(d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
             CK(hipMalloc(&d_tab, entries * 32)); CK(hipMemset(d_tab, 1, entries * 32));
+            float a1 = time_it([&] { hipLaunchKernelGGL(k_one_lane<1>, dim3(BLOCKS), dim3(THREADS), 0, 0, d_tab, d_idx, d_out); });
+            float b1 = time_it([&] { hipLaunchKernelGGL(k_lane_pair<1>, dim3(BLOCKS), dim3(THREADS), 0, 0, d_tab, d_idx, d_out); });
+            float b2 = time_it([&] { hipLaunchKernelGGL(k_lane_pair<2>, dim3(BLOCKS), dim3(THREADS), 0, 0, d_tab, d_idx, d_out); });
+            float f1 = time_it([&] { hipLaunchKernelGGL(k_f64<1>, dim3(BLOCKS), dim3(THREADS), 0, 0, (const double*)d_tab, d_idx, d_out); });
+            float f2 = time_it([&] { hipLaunchKernelGGL(k_f64<2>, dim3(BLOCKS), dim3(THREADS), 0, 0, (const double*)d_tab, d_idx, d_out); });
+            printf("entries %8zu %s : one lane U=1 %6.1f | lane pair U=1 %6.1f U=2 %6.1f | f64 U=1 %6.1f U=2 %6.1f us\n", entries,
+                   sorted ? "sorted" : "random", a1, b1, b2, f1, f2);
             float a2 = time_it([&] { hipLaunchKernelGGL(k_one_lane<2>, dim3(BLOCKS), dim3(THREADS), 0, 0, d_tab, d_idx, d_out); });
             float a4 = time_it([&] { hipLaunchKernelGGL(k_one_lane<4>, dim3(BLOCKS), dim3(THREADS), 0, 0, d_tab, d_idx, d_out); });
             float b4 = time_it([&] { hipLaunchKernelGGL(k_lane_pair<4>, dim3(BLOCKS), dim3(THREADS), 0, 0, d_tab, d_idx, d_out); });
