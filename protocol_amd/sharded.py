@@ -20,33 +20,36 @@ from . import _ffi
 from .graph import DistributedPlan, Graph, R_MODULUS
 
 
-def _all_reduce_np(arr, signed_view, op, group, world, comm_device):
+def _all_reduce_np(arr, signed_view, op, group, world, comm_device, always=False):
     """All-reduce of a numpy array of unsigned integers (summed or maximised as the signed type of the same width:
     per-peer degree sums stay far below 2^31, row sums below 2^63)."""
-    if world == 1:
+    if world == 1 and not always:
         return arr
     t = torch.from_numpy(arr.view(signed_view)).to(comm_device)
     dist.all_reduce(t, op=op, group=group)
     return t.cpu().numpy().view(arr.dtype)
 
 
-def distributed_plan(n, frm, to, value_u32, member=None, group=None, world=1, rank=0, comm_device=None, **opts):
+def distributed_plan(n, frm, to, value_u32, member=None, group=None, world=1, rank=0, comm_device=None,
+                     always_collective=False, **opts):
     """The share of `rank` laid out from rank-local attestations (every attestation of an attester on one rank), ready for
     DistributedPlan.finish() / finish_host().  Collectives: three all-reduces of per-peer figures (8 + 4 + 4 bytes per
     peer), one of a scalar, one all-gather of the record counts and three all-to-alls of the edge records (12 bytes per
     surviving edge in all).  `comm_device`: where tensors handed to a collective live (the GPU for RCCL, the host for
-    gloo)."""
+    gloo).  `always_collective`: run the collectives with a single rank too (each is then the identity): the way to
+    take this function's RCCL calls on a one-GPU box."""
     comm_device = comm_device or torch.device("cpu")
     plan = DistributedPlan(n, frm, to, value_u32, member=member)
     row_sum, in_deg, out_deg, vmax = plan.local_stats()
-    row_sum = _all_reduce_np(row_sum, np.int64, dist.ReduceOp.SUM, group, world, comm_device)
-    in_deg = _all_reduce_np(in_deg, np.int32, dist.ReduceOp.SUM, group, world, comm_device)
-    out_deg = _all_reduce_np(out_deg, np.int32, dist.ReduceOp.SUM, group, world, comm_device)
-    vmax = int(_all_reduce_np(np.array([vmax], dtype=np.uint32), np.int32, dist.ReduceOp.MAX, group, world, comm_device)[0])
+    ar = lambda a, view, op: _all_reduce_np(a, view, op, group, world, comm_device, always_collective)
+    row_sum = ar(row_sum, np.int64, dist.ReduceOp.SUM)
+    in_deg = ar(in_deg, np.int32, dist.ReduceOp.SUM)
+    out_deg = ar(out_deg, np.int32, dist.ReduceOp.SUM)
+    vmax = int(ar(np.array([vmax], dtype=np.uint32), np.int32, dist.ReduceOp.MAX)[0])
     plan.set_global_stats(row_sum, in_deg, out_deg, vmax, world, rank, **opts)
     del row_sum, in_deg, out_deg
     outgoing = [plan.outgoing(s) for s in range(world)]
-    if world == 1:
+    if world == 1 and not always_collective:
         plan.add_incoming(*outgoing[0])
         return plan
     send = [len(o[0]) for o in outgoing]
@@ -105,7 +108,8 @@ class ShardedGraph:
     def _build_from_local(self, n, frm, to, value_u32, member, variants, dev_index, n_chunks, **build_kw):
         comm = self.device if dist.is_initialized() and dist.get_backend(self.group) == "nccl" else torch.device("cpu")
         plan = distributed_plan(n, frm, to, value_u32, member=member, group=self.group, world=self.world, rank=self.rank,
-                                comm_device=comm, variants=variants, device=dev_index, n_chunks=n_chunks, **build_kw)
+                                comm_device=comm, always_collective=self.always_exchange, variants=variants, device=dev_index,
+                                n_chunks=n_chunks, **build_kw)
         graph = plan.finish()
         plan.close()
         return graph

@@ -153,7 +153,10 @@ def _nccl_worker(rank, world, port, case, ret):
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     n, member, frm, to, val, iters = case[:6]
     chunks = case[6] if len(case) > 6 else 1
-    sg = ShardedGraph(n, frm, to, value_u32=val, member=member, device=dev, always_exchange=True, n_chunks=chunks)
+    local = len(case) > 7 and case[7]
+    # local: the layout through the rank-local path, whose all-reduces and all-to-all then run on device tensors over RCCL
+    sg = ShardedGraph(n, frm, to, value_u32=val, member=member, device=dev, always_exchange=True, n_chunks=chunks,
+                      local_attestations=local)
     assert sg.n_chunks == chunks
     ret["fr"] = sg.converge_fr(iters, 1000).tobytes()      # conservation checked through the 32-byte tensor gather
     ret["f64"] = sg.converge_f64(iters, 1000.0).tolist()
@@ -161,8 +164,8 @@ def _nccl_worker(rank, world, port, case, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("chunks", [1, 3])
-def test_rccl_backend_with_the_one_rank_a_single_gpu_allows(chunks):
+@pytest.mark.parametrize("chunks,local", [(1, False), (3, False), (1, True)])
+def test_rccl_backend_with_the_one_rank_a_single_gpu_allows(chunks, local):
     """The driver's RCCL calls themselves (in-place all_gather_into_tensor of the segments, the 32-byte gather of the
     conservation check) with backend nccl: one rank is all a single GPU allows, so the collective copies the vector
     onto itself, but it is the same call, on the same tensors, that N ranks make."""
@@ -181,7 +184,7 @@ def test_rccl_backend_with_the_one_rank_a_single_gpu_allows(chunks):
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 29500 + (os.getpid() + 7) % 2000
-    mp.spawn(_nccl_worker, args=(1, port, (n, member, frm, to, val, iters, chunks), ret), nprocs=1, join=True)
+    mp.spawn(_nccl_worker, args=(1, port, (n, member, frm, to, val, iters, chunks, local), ret), nprocs=1, join=True)
     assert ret["fr"] == exp.tobytes()
     got = np.array(ret["f64"], dtype=np.longdouble)
     assert float(np.abs(got - eld).sum() / np.abs(eld).sum()) <= 1e-9
