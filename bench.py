@@ -301,9 +301,14 @@ def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu):
         achieved = alg / launch_s / 1e9
         kernel = "k_step_f64_blocked<u8>" if variant == "f64" else fr_kernel
         rec = counter_record(wl, kernel, launch_s * 1e6) if world == 1 else None
+        per_iteration_us = elapsed / steps / NUM_ITER * 1e6
         results[variant] = {
             "value": nnz * NUM_ITER * steps / elapsed,
             "ms_per_step": elapsed / steps * 1e3,
+            # N > 1: what an iteration spends outside this rank's launches (the exchange and the waits for the slowest
+            # rank), from the wall time of a step and the event time of rank 0's launches
+            "iteration_us": {"total": per_iteration_us, "launches": launch_s * 1e6,
+                             "exchange_and_waits": max(0.0, per_iteration_us - launch_s * 1e6)} if world > 1 else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": rec["traffic_bytes"] if rec else None,
@@ -384,6 +389,8 @@ def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu):
         "checks": checks,
         "setup_s": {"generate": t_gen, "build_and_upload": t_build},
     }
+    if world > 1:
+        line["iteration_us"] = head["iteration_us"]
     if "fr" in results and "f64" in results:
         line["fr_exact"] = dict(results["fr"], dtype="fr254 (8x32-bit limbs)", unit="edge-iterations/s")
     sg.graph.close()

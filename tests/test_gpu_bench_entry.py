@@ -34,3 +34,5 @@ def test_two_ranks_started_by_bench_itself(chunks):
     assert line["checks"]["f64_sum_rel_err"] < 1e-12
     assert line["value"] > 0 and line["roofline"]["kernel"].startswith("k_step_f64_blocked")
     assert line["cpu_baseline"] is None and line["vs_baseline"] is None
+    it = line["iteration_us"]                                         # where an iteration's time goes: launches / the rest
+    assert it["total"] > 0 and abs(it["launches"] + it["exchange_and_waits"] - it["total"]) < 1e-6 * it["total"] + 1e-9
