@@ -472,8 +472,8 @@ int lay_out_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned
         grp_table.assign((size_t)B * gpb, 0xFFFFFFFFu);
         ptr.assign((size_t)B + 1, 0);
         std::vector<uint32_t> used(B, 0);
-        std::vector<uint64_t> load(B, 0);
-        typedef std::pair<uint64_t, uint32_t> Load;   // (edges so far, workgroup)
+        std::vector<uint64_t> load(B, 0), edges(B, 0);   // load: edges weighted by the cost of the workgroup's XCD
+        typedef std::pair<uint64_t, uint32_t> Load;   // (load so far, workgroup)
         auto pass = [&](uint32_t g0, uint32_t g1, uint32_t n_blocks) {
             std::vector<uint32_t> by_weight(g1 - g0);
             std::iota(by_weight.begin(), by_weight.end(), g0);
@@ -487,13 +487,14 @@ int lay_out_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned
                 d.block[gi] = bb;
                 d.slot[gi] = used[bb];
                 grp_table[(size_t)bb * gpb + used[bb]] = gi;
-                load[bb] += grp_edges[gi];
+                load[bb] += grp_edges[gi] * opt.xcd_cost[bb % 8];
+                edges[bb] += grp_edges[gi];
                 if (++used[bb] < gpb) heap.push(Load(load[bb], bb));   // a full workgroup leaves the heap
             }
         };
         pass(first_dangling_group, n_groups, dblocks);
         pass(0, first_dangling_group, B);
-        for (uint32_t bb = 0; bb < B; ++bb) ptr[bb + 1] = ptr[bb] + load[bb];
+        for (uint32_t bb = 0; bb < B; ++bb) ptr[bb + 1] = ptr[bb] + edges[bb];
         return d;
     };
     const Deal d64 = deal(geo.f64_blocks, geo.f64_rb / BLOCK_GROUP, geo.f64_dblocks, g.bk_grp, g.bk_ptr);

@@ -41,6 +41,10 @@ struct BuildOpts {
     uint32_t hot_prefix = 16384; // the most-attesting (most gathered) peers take the first positions: one contiguous prefix of the vector
     uint32_t f64_blocks = 256;   // workgroups of the f64 variant (one per CU)
     uint32_t n_chunks = 1;       // pieces a segment is exchanged in (see Geometry::n_chunks); honoured where both variants run the blocked sweep
+    // Relative time a workgroup on XCD x (workgroup b runs on XCD b mod 8) needs per edge of a blocked sweep, in 1/1024
+    // (1024 = the same everywhere): the deal levels edges x cost instead of edges.  Measured per device by
+    // xcd_cost_factors (engine.hpp); a plan made without a device keeps the default.
+    uint32_t xcd_cost[8] = {1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024};
 };
 
 struct HostGraph {

@@ -85,8 +85,16 @@ static void read_env(BuildOpts& bo) {
     if (const char* e = getenv("ET_F64_BLOCKS")) bo.f64_blocks = (uint32_t)atoi(e);
 }
 
+static int plan_build(uint32_t n, const uint8_t* member, uint64_t n_edges, const uint32_t* from, const uint32_t* to,
+                      const uint32_t* value_u32, const et_fr* value_fr, const et_build_opts* opts, bool for_device, et_plan** out);
+
 int et_plan_build(uint32_t n, const uint8_t* member, uint64_t n_edges, const uint32_t* from, const uint32_t* to,
                   const uint32_t* value_u32, const et_fr* value_fr, const et_build_opts* opts, et_plan** out) {
+    return plan_build(n, member, n_edges, from, to, value_u32, value_fr, opts, false, out);
+}
+
+static int plan_build(uint32_t n, const uint8_t* member, uint64_t n_edges, const uint32_t* from, const uint32_t* to,
+                      const uint32_t* value_u32, const et_fr* value_fr, const et_build_opts* opts, bool for_device, et_plan** out) {
     if (!out) return ET_E_INVALID_ARG;
     BuildInput in;
     in.n = n;
@@ -102,6 +110,7 @@ int et_plan_build(uint32_t n, const uint8_t* member, uint64_t n_edges, const uin
     int variants, device;
     read_opts(opts, bo, variants, device);
     read_env(bo);
+    if (for_device) xcd_cost_factors(device, bo.xcd_cost);
     std::unique_ptr<et_plan> p(new et_plan());
     std::string err;
     int rc = build_graph(in, bo, p->h, err);
@@ -156,7 +165,7 @@ int et_graph_build(uint32_t n, const uint8_t* member, uint64_t n_edges, const ui
                    const uint32_t* value_u32, const et_fr* value_fr, const et_build_opts* opts, et_graph** out) {
     if (!out) return ET_E_INVALID_ARG;
     et_plan* p = nullptr;
-    int rc = et_plan_build(n, member, n_edges, from, to, value_u32, value_fr, opts, &p);
+    int rc = plan_build(n, member, n_edges, from, to, value_u32, value_fr, opts, true, &p);   // levelled for this card's XCDs
     if (rc) return rc;
     rc = et_graph_from_plan(p, opts, out);
     et_plan_free(p);

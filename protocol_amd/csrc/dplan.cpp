@@ -193,8 +193,9 @@ int et_dplan_info_get(const et_dplan* p, et_graph_info* info) {
     return ET_OK;
 }
 
-static int lay_out(et_dplan* p) {
+static int lay_out(et_dplan* p, bool for_device) {
     if (p->stage != 2) { set_error("finish follows set_global_stats and the records"); return ET_E_INVALID_ARG; }
+    if (for_device) xcd_cost_factors(p->device, p->opt.xcd_cost);
     p->out_src = std::vector<uint32_t>(); p->out_row = std::vector<uint32_t>(); p->out_val = std::vector<uint32_t>();
     std::string err;
     int rc = plan_segment_from_records(p->pc.g, p->opt, p->opt.seg, p->in_src, p->in_row, p->in_val, err);
@@ -206,7 +207,7 @@ static int lay_out(et_dplan* p) {
 
 int et_dplan_finish(et_dplan* p, et_graph** out) {
     if (!p || !out) return ET_E_INVALID_ARG;
-    int rc = lay_out(p);
+    int rc = lay_out(p, true);
     if (rc) return rc;
     DeviceGraph* dg = nullptr;
     rc = DeviceGraph::create(p->pc.g, p->variants, p->device, &dg);
@@ -217,7 +218,7 @@ int et_dplan_finish(et_dplan* p, et_graph** out) {
 
 int et_dplan_finish_host(et_dplan* p, et_plan** out) {
     if (!p || !out) return ET_E_INVALID_ARG;
-    int rc = lay_out(p);
+    int rc = lay_out(p, false);
     if (rc) return rc;
     std::unique_ptr<et_plan> plan(new et_plan());
     plan->h = std::move(p->pc.g);

@@ -10,6 +10,9 @@
 // order.  The exact variant produces identical bits on every run and every GPU count; the f64
 // variant accumulates a row with LDS atomics whose order is not fixed, so its last bits may vary.
 #include <hip/hip_runtime.h>
+#include <array>
+#include <map>
+#include <mutex>
 
 #include <algorithm>
 #include <atomic>
@@ -1157,6 +1160,73 @@ static bool pack_records(const Geometry& geo, uint32_t B, const std::vector<uint
         }
     });
     return fits;
+}
+
+// ---------------------------------------------------------------------------------------------
+// XCD probe: what a workgroup's gathers cost on each XCD
+// ---------------------------------------------------------------------------------------------
+// One 1024-thread workgroup per CU, as the sweeps launch; every workgroup walks a 32 MB table of 32-byte entries from
+// one end to the other the way a sweep walks the vector -- in each pass its 1024 threads gather one entry out of each of
+// 1024 consecutive groups of `n_entries / (passes * 1024)` entries, a different one per workgroup -- and reports how
+// long it took.
+__global__ __launch_bounds__(1024) void k_xcd_probe(const uint4* __restrict__ tab, uint32_t n_entries, uint32_t passes,
+                                                    unsigned long long* __restrict__ ticks, uint32_t* __restrict__ sink) {
+    __syncthreads();
+    const uint64_t t0 = wall_clock64();
+    const uint32_t group = n_entries / (passes * 1024u);
+    uint32_t x = (blockIdx.x * 1024u + threadIdx.x) * 2654435761u + 12345u, acc = 0;
+    for (uint32_t k = 0; k < passes; ++k) {
+        x = x * 1664525u + 1013904223u;
+        const uint4* p = tab + 2 * ((size_t)(k * 1024u + threadIdx.x) * group + (x >> 8) % group);
+        const uint4 lo = p[0], hi = p[1];
+        acc ^= lo.x ^ hi.w;
+        if ((k & 7) == 7) __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ticks[blockIdx.x] = wall_clock64() - t0;
+    if (acc == 0x9e3779b9u) sink[0] = acc;
+}
+
+void xcd_cost_factors(int device, uint32_t out[8]) {
+    static std::mutex lock;
+    static std::map<int, std::array<uint32_t, 8>> cache;
+    for (int x = 0; x < 8; ++x) out[x] = 1024;
+    if (const char* e = getenv("ET_XCD_BALANCE")) if (atoi(e) == 0) return;
+    std::lock_guard<std::mutex> guard(lock);
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return;
+    auto hit = cache.find(device);
+    if (hit != cache.end()) { for (int x = 0; x < 8; ++x) out[x] = hit->second[x]; return; }
+    std::array<uint32_t, 8> f;
+    f.fill(1024);
+    const uint32_t n_entries = 1u << 20, blocks = 256, passes = 64, reps = 6;
+    uint4* tab = nullptr;
+    unsigned long long* d_ticks = nullptr;
+    uint32_t* d_sink = nullptr;
+    bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(&tab, (size_t)n_entries * 32) == hipSuccess &&
+              hipMalloc(&d_ticks, blocks * sizeof(unsigned long long)) == hipSuccess && hipMalloc(&d_sink, 64) == hipSuccess &&
+              hipMemset(tab, 1, (size_t)n_entries * 32) == hipSuccess;
+    double per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t r = 0; ok && r < reps; ++r) {
+        hipLaunchKernelGGL(k_xcd_probe, dim3(blocks), dim3(1024), 0, 0, tab, n_entries, passes, d_ticks, d_sink);
+        std::vector<unsigned long long> t(blocks);
+        ok = hipMemcpy(t.data(), d_ticks, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok && r > 0)                                   // the first launch warms the table into the caches
+            for (uint32_t b = 0; b < blocks; ++b) per_xcd[b % 8] += (double)t[b];
+    }
+    if (tab) (void)hipFree(tab);
+    if (d_ticks) (void)hipFree(d_ticks);
+    if (d_sink) (void)hipFree(d_sink);
+    if (ok) {
+        double lo = per_xcd[0], hi = per_xcd[0];
+        for (int x = 1; x < 8; ++x) { lo = std::min(lo, per_xcd[x]); hi = std::max(hi, per_xcd[x]); }
+        if (lo > 0 && hi / lo >= 1.01 && hi / lo <= 1.25)
+            for (int x = 0; x < 8; ++x) f[x] = (uint32_t)(1024.0 * per_xcd[x] / lo + 0.5);
+    }
+    (void)hipGetLastError();
+    cache[device] = f;
+    for (int x = 0; x < 8; ++x) out[x] = f[x];
+    if (getenv("ET_XCD_VERBOSE"))
+        fprintf(stderr, "xcd cost factors (device %d): %u %u %u %u %u %u %u %u\n", device, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
 }
 
 int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGraph** out) {

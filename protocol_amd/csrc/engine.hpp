@@ -15,6 +15,11 @@ namespace et {
 void set_error(const std::string& s);
 const char* last_error();
 
+// Per-XCD cost factors for BuildOpts::xcd_cost, measured once per device and process by a short gather probe (the XCDs
+// of a card do not serve L2 misses equally fast; workgroup b of a launch runs on XCD b mod 8).  All 1024 when the
+// spread is below 1 %, when ET_XCD_BALANCE=0, or when the probe fails.
+void xcd_cost_factors(int device, uint32_t out[8]);
+
 struct DeviceGraph {
     int device = -1;
     int variants = 0;

@@ -269,7 +269,9 @@ int et_sharded_create(uint32_t n, const uint8_t* member, uint64_t n_edges, const
     s->g.assign(n_devices, nullptr);
     for (uint32_t r = 0; r < n_devices; ++r) {
         HostGraph h;
-        if ((rc = plan_segment(pc, bo, r, h, err))) { set_error(err); return rc; }
+        BuildOpts bs = bo;
+        xcd_cost_factors(devices[r], bs.xcd_cost);      // each share levelled for the XCDs of the card it runs on
+        if ((rc = plan_segment(pc, bs, r, h, err))) { set_error(err); return rc; }
         if ((rc = DeviceGraph::create(h, s->variants, devices[r], &s->g[r]))) return rc;
     }
     s->vec_len = s->g[0]->vec_len;
