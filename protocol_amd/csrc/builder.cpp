@@ -1,6 +1,7 @@
 #include "builder.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <numeric>
 #include <queue>
@@ -275,6 +276,198 @@ int filter_edges(const BuildInput& in, PlanCommon& pc, RowSums& sums, PeerStats&
     return ET_OK;
 }
 
+// Step 5b (one share, both variants on the blocked sweep): positions that put a source next to the sources the same
+// workgroup gathers.
+//
+// A blocked sweep is bound by the 128-byte lines a workgroup's gathers pull into its L1.  In degree order a source with
+// few out-edges costs one line per edge: its line-mates are gathered by other workgroups.  The rows of a workgroup are
+// 16-row groups of consecutive positions, so a peer's position fixes both where its score lives and which workgroup sums
+// its row.  Peers with at most `max_deg` out-edges are therefore placed by label propagation under capacity: a peer joins
+// the workgroup that holds most of the peers it rates or is rated by (each such edge then reads from the workgroup's own
+// 16-row groups, every line of which it uses in full), and inside a workgroup's peers the order is by the workgroup of
+// another rated peer, so that one more edge per source finds its line-mates gathered together.  The most-attesting peers
+// keep their degree order in front.  Row groups are dealt here (`grp_hint`); lay_out_segment follows the hints where the
+// workgroup has room and levels the rest.  Positions are internal: results are un-permuted by `pos_of_ext` as before.
+static void cluster_cold_sources(PlanCommon& pc, const PeerStats& st, const BuildOpts& opt) {
+    HostGraph& g = pc.g;
+    const Geometry& geo = g.geo;
+    const BuildInput& in = pc.in;
+    std::vector<uint32_t>& order = pc.order;
+    const uint32_t n = in.n, n_active = geo.n_active, B = geo.f64_blocks;
+    const uint32_t max_deg = getenv("ET_AFFINITY_MAX_DEG") ? (uint32_t)atoi(getenv("ET_AFFINITY_MAX_DEG")) : 16;
+    const uint32_t rounds = getenv("ET_AFFINITY_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("ET_AFFINITY_ROUNDS"))) : 3;
+    const uint32_t n_agroups = geo.n_active_pad / BLOCK_GROUP;
+    if (B < 2 || n_agroups / B < 16) return;
+    const uint32_t H = n_agroups / B - 3;          // hinted groups per workgroup; the rest is dealt for balance
+    const uint32_t NONE = 0xFFFFFFFFu;
+    auto by_out = [&](uint32_t a, uint32_t b) {
+        if (st.out_deg[a] != st.out_deg[b]) return st.out_deg[a] > st.out_deg[b];
+        return a < b;
+    };
+    // ---- classes: front (hot prefix, then the other peers above max_deg by out-degree), cold ----
+    const uint32_t h1 = std::min<uint32_t>(n_active, opt.hot_prefix);
+    std::vector<uint32_t> front(order.begin(), order.begin() + h1), mid, cold;
+    for (uint32_t r = h1; r < n_active; ++r) (st.out_deg[order[r]] > max_deg ? mid : cold).push_back(order[r]);
+    const uint32_t pad = (uint32_t)((BLOCK_GROUP - (front.size() + mid.size()) % BLOCK_GROUP) % BLOCK_GROUP);
+    if (cold.size() < (size_t)pad + (size_t)B * BLOCK_GROUP * 8) return;
+    if (pad) {
+        std::nth_element(cold.begin(), cold.begin() + pad, cold.end(), by_out);
+        mid.insert(mid.end(), cold.begin(), cold.begin() + pad);
+        cold.erase(cold.begin(), cold.begin() + pad);
+        std::sort(cold.begin(), cold.end());
+    }
+    std::sort(mid.begin(), mid.end(), by_out);
+    front.insert(front.end(), mid.begin(), mid.end());
+    const uint32_t n_front = (uint32_t)front.size(), n_fg = n_front / BLOCK_GROUP, n_cold = (uint32_t)cold.size();
+    if ((n_fg + B - 1) / B + 8 > H) return;
+    // ---- the front's groups: heaviest first to the lightest workgroup, equal counts ----
+    std::vector<uint32_t> hint(n_agroups, NONE), used(B, 0), label(n, NONE);
+    std::vector<uint64_t> load(B, 0);
+    uint64_t front_edges = 0, cold_edges = 0;
+    {
+        std::vector<uint64_t> w(n_fg, 0);
+        for (uint32_t r = 0; r < n_front; ++r) w[r / BLOCK_GROUP] += st.in_deg[front[r]];
+        std::vector<uint32_t> by_w(n_fg);
+        std::iota(by_w.begin(), by_w.end(), 0u);
+        std::stable_sort(by_w.begin(), by_w.end(), [&](uint32_t x, uint32_t y) { return w[x] > w[y]; });
+        typedef std::pair<uint64_t, uint32_t> Load;
+        std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+        const uint32_t cap = (n_fg + B - 1) / B;
+        for (uint32_t b = 0; b < B; ++b) heap.push(Load(0, b));
+        for (uint32_t gi : by_w) {
+            const uint32_t b = heap.top().second;
+            heap.pop();
+            hint[gi] = b;
+            load[b] += w[gi] * opt.xcd_cost[b % 8];
+            front_edges += w[gi];
+            if (++used[b] < cap) heap.push(Load(load[b], b));
+        }
+        for (uint32_t r = 0; r < n_front; ++r) label[front[r]] = hint[r / BLOCK_GROUP];
+    }
+    // ---- cold peers: who rates them (cold raters only: a front source's lines are gathered by every workgroup anyway) ----
+    std::vector<uint32_t> cidx(n, NONE);
+    for (uint32_t k = 0; k < n_cold; ++k) { cidx[cold[k]] = k; cold_edges += st.in_deg[cold[k]]; }
+    std::vector<uint64_t> rin_ptr((size_t)n_cold + 1, 0);
+    for (uint32_t k = 0; k < n_cold; ++k) {
+        const uint32_t f = cold[k];
+        for (uint64_t e = pc.out_ptr[f]; e < pc.out_ptr[f + 1]; ++e) {
+            if (pc.drop[e]) continue;
+            const uint32_t t = cidx[in.to[pc.kept[e]]];
+            if (t != NONE) ++rin_ptr[t + 1];
+        }
+    }
+    for (uint32_t k = 0; k < n_cold; ++k) rin_ptr[k + 1] += rin_ptr[k];
+    std::vector<uint32_t> rin(rin_ptr[n_cold]);
+    {
+        std::vector<uint64_t> cur(rin_ptr.begin(), rin_ptr.end() - 1);
+        for (uint32_t k = 0; k < n_cold; ++k) {
+            const uint32_t f = cold[k];
+            for (uint64_t e = pc.out_ptr[f]; e < pc.out_ptr[f + 1]; ++e) {
+                if (pc.drop[e]) continue;
+                const uint32_t t = cidx[in.to[pc.kept[e]]];
+                if (t != NONE) rin[cur[t]++] = f;
+            }
+        }
+    }
+    // ---- label propagation under capacity ----
+    // A workgroup's rows and its in-edges must both come out level.  Rows: every workgroup has room for the same number of
+    // hinted groups.  Edges: a workgroup takes a peer only while its edge count stays on the straight line from what the
+    // front's groups gave it to the common target, reached when its room is full (plus a small allowance); a peer nobody
+    // can take that way goes to the workgroup furthest below its line.
+    std::vector<uint32_t> rows_cap(B);
+    uint64_t cold_room = 0;
+    for (uint32_t b = 0; b < B; ++b) { rows_cap[b] = (H - used[b]) * BLOCK_GROUP; cold_room += rows_cap[b]; }
+    if (cold_room > n_cold) return;
+    uint64_t cost_sum = 0;
+    for (uint32_t b = 0; b < B; ++b) cost_sum += opt.xcd_cost[b % 8];
+    const long double hinted_edges = (long double)front_edges + (long double)cold_edges * cold_room / n_cold;
+    const double target = (double)(hinted_edges * ((long double)cost_sum / B) / B), allowance = target * 0.002;
+    std::vector<uint32_t> rows_left(B), votes(B, 0), touched;
+    std::vector<double> load_r(B), slope(B);
+    for (uint32_t b = 0; b < B; ++b) slope[b] = (target - (double)load[b]) / rows_cap[b];
+    auto line = [&](uint32_t b) { return (double)load[b] + slope[b] * (rows_cap[b] - rows_left[b] + 1); };
+    // visit order: a fixed stride through the cold peers, coprime to their number
+    uint64_t stride = (uint64_t)(n_cold * 0.6180339887498949) | 1;
+    while (std::gcd<uint64_t, uint64_t>(stride, n_cold) != 1) stride += 2;
+    const bool stats = getenv("ET_BUILD_STATS") != nullptr;
+    for (uint32_t round = 0; round < rounds; ++round) {
+        rows_left = rows_cap;
+        for (uint32_t b = 0; b < B; ++b) load_r[b] = (double)load[b];
+        uint64_t by_vote = 0, moved = 0;
+        for (uint32_t step = 0; step < n_cold; ++step) {
+            const uint32_t k = (uint32_t)(((uint64_t)step * stride) % n_cold), f = cold[k];
+            touched.clear();
+            auto vote = [&](uint32_t ext) {
+                const uint32_t l = label[ext];       // this round's label if the peer was visited already, else the last round's
+                if (l == NONE) return;
+                if (votes[l]++ == 0) touched.push_back(l);
+            };
+            for (uint64_t e = pc.out_ptr[f]; e < pc.out_ptr[f + 1]; ++e) if (!pc.drop[e]) vote(in.to[pc.kept[e]]);
+            for (uint64_t e = rin_ptr[k]; e < rin_ptr[k + 1]; ++e) vote(rin[e]);
+            uint32_t best = NONE;
+            for (uint32_t l : touched) {
+                if (rows_left[l] && load_r[l] + (double)st.in_deg[f] * opt.xcd_cost[l % 8] <= line(l) + allowance &&
+                    (best == NONE || votes[l] > votes[best] || (votes[l] == votes[best] && rows_left[l] > rows_left[best])))
+                    best = l;
+            }
+            for (uint32_t l : touched) votes[l] = 0;
+            by_vote += best != NONE;
+            if (best == NONE) {
+                double worst = 0;
+                for (uint32_t b = 0; b < B; ++b) {
+                    if (!rows_left[b]) continue;
+                    const double behind = line(b) - load_r[b];
+                    if (best == NONE || behind > worst) { best = b; worst = behind; }
+                }
+            }
+            moved += label[f] != best;
+            label[f] = best;
+            if (best != NONE) { --rows_left[best]; load_r[best] += (double)st.in_deg[f] * opt.xcd_cost[best % 8]; }
+        }
+        if (stats) {
+            uint64_t local = 0, all = 0;
+            for (uint32_t k = 0; k < n_cold; ++k) {
+                const uint32_t f = cold[k];
+                for (uint64_t e = pc.out_ptr[f]; e < pc.out_ptr[f + 1]; ++e) if (!pc.drop[e]) { ++all; local += label[f] != NONE && label[in.to[pc.kept[e]]] == label[f]; }
+            }
+            double lo = 1e300, hi = 0;
+            for (uint32_t b = 0; b < B; ++b) { lo = std::min(lo, load_r[b]); hi = std::max(hi, load_r[b]); }
+            fprintf(stderr, "[et build] clustering round %u: %u cold peers of %u active, %llu placed by vote, %llu changed, %llu of their %llu out-edges stay in the workgroup; load %.0f..%.0f of %.0f\n",
+                    round, n_cold, n_active, (unsigned long long)by_vote, (unsigned long long)moved, (unsigned long long)local, (unsigned long long)all, lo, hi, target);
+        }
+    }
+    // ---- order: front, then workgroup by workgroup, inside by the workgroup of another rated peer; then the rest ----
+    std::vector<uint64_t> key(n_cold);
+    for (uint32_t k = 0; k < n_cold; ++k) {
+        const uint32_t f = cold[k], own = label[f];
+        touched.clear();
+        for (uint64_t e = pc.out_ptr[f]; e < pc.out_ptr[f + 1]; ++e) {
+            if (pc.drop[e]) continue;
+            const uint32_t l = label[in.to[pc.kept[e]]];
+            if (l == NONE || l == own) continue;
+            if (votes[l]++ == 0) touched.push_back(l);
+        }
+        uint32_t second = B;
+        // ties are broken by a hash of (peer, workgroup): every workgroup gets its share of the second-level runs
+        auto mix = [&](uint32_t l) { uint64_t z = ((uint64_t)f << 20 ^ l) * 0x9E3779B97F4A7C15ull; return z ^ (z >> 29); };
+        for (uint32_t l : touched) if (second == B || votes[l] > votes[second] || (votes[l] == votes[second] && mix(l) < mix(second))) second = l;
+        for (uint32_t l : touched) votes[l] = 0;
+        key[k] = ((uint64_t)(own == NONE ? B : own) << 32) | second;
+    }
+    std::vector<uint32_t> by_key(n_cold);
+    std::iota(by_key.begin(), by_key.end(), 0u);
+    std::sort(by_key.begin(), by_key.end(), [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] < key[b] : cold[a] < cold[b]; });
+    for (uint32_t r = 0; r < n_front; ++r) order[r] = front[r];
+    for (uint32_t k = 0; k < n_cold; ++k) {
+        const uint32_t r = n_front + k, own = (uint32_t)(key[by_key[k]] >> 32);
+        order[r] = cold[by_key[k]];
+        if (own < B) hint[r / BLOCK_GROUP] = own;    // a workgroup's peers fill whole groups: its room is a multiple of the group
+    }
+    for (uint32_t r = 0; r < n_active; ++r) g.pos_of_ext[order[r]] = r;     // one share: position = rank
+    g.grp_hint.swap(hint);
+    g.hint_blocks = B;
+}
+
 int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& pc, std::string& err) {
     if (opt.n_seg == 0 || opt.seg >= opt.n_seg) {
         err = "bad segment";
@@ -286,6 +479,11 @@ int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& pc, std:
     if (rc) return rc;
     HostGraph& g = pc.g;
     if ((rc = layout_common(in.n, in.member, g.values_are_u32, pc.dangling, st, opt, g, pc.order, err))) return rc;
+    {
+        const char* e = getenv("ET_AFFINITY");
+        if (opt.n_seg == 1 && g.geo.n_chunks == 1 && g.geo.fr_blocks != 0 && g.geo.fr_blocks == g.geo.f64_blocks && !(e && atoi(e) == 0))
+            cluster_cold_sources(pc, st, opt);
+    }
     // ---- 6. per-position source factors ------------------------------------------------------
     fill_factors(g, pc.order.data(), g.geo.n_active, [&](uint32_t i) { return g.values_are_u32 ? Fr::from_u64(sums.u64[i]) : sums.fr[i]; },
                  [&](uint32_t i) { return g.values_are_u32 ? 1.0 / (double)sums.u64[i] : (double)(1.0L / sums.ld[i]); });
@@ -474,26 +672,35 @@ int lay_out_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned
         std::vector<uint32_t> used(B, 0);
         std::vector<uint64_t> load(B, 0), edges(B, 0);   // load: edges weighted by the cost of the workgroup's XCD
         typedef std::pair<uint64_t, uint32_t> Load;   // (load so far, workgroup)
-        auto pass = [&](uint32_t g0, uint32_t g1, uint32_t n_blocks) {
-            std::vector<uint32_t> by_weight(g1 - g0);
-            std::iota(by_weight.begin(), by_weight.end(), g0);
+        auto place = [&](uint32_t gi, uint32_t bb) {
+            d.block[gi] = bb;
+            d.slot[gi] = used[bb];
+            grp_table[(size_t)bb * gpb + used[bb]] = gi;
+            load[bb] += grp_edges[gi] * opt.xcd_cost[bb % 8];
+            edges[bb] += grp_edges[gi];
+            ++used[bb];
+        };
+        auto pass = [&](uint32_t g0, uint32_t g1, uint32_t n_blocks, bool hinted) {
+            std::vector<uint32_t> by_weight;
+            by_weight.reserve(g1 - g0);
+            // groups placed with the sources their workgroup gathers (cluster_cold_sources) go where they were meant to
+            for (uint32_t gi = g0; gi < g1; ++gi) {
+                const uint32_t h = hinted && gi < g.grp_hint.size() ? g.grp_hint[gi] : 0xFFFFFFFFu;
+                if (h < n_blocks && used[h] < gpb) place(gi, h);
+                else by_weight.push_back(gi);
+            }
             std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t x, uint32_t y) { return grp_edges[x] > grp_edges[y]; });
             std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
             for (uint32_t bb = 0; bb < n_blocks; ++bb) if (used[bb] < gpb) heap.push(Load(load[bb], bb));
             for (uint32_t gi : by_weight) {
-                Load l = heap.top();
+                const uint32_t bb = heap.top().second;
                 heap.pop();
-                const uint32_t bb = l.second;
-                d.block[gi] = bb;
-                d.slot[gi] = used[bb];
-                grp_table[(size_t)bb * gpb + used[bb]] = gi;
-                load[bb] += grp_edges[gi] * opt.xcd_cost[bb % 8];
-                edges[bb] += grp_edges[gi];
-                if (++used[bb] < gpb) heap.push(Load(load[bb], bb));   // a full workgroup leaves the heap
+                place(gi, bb);
+                if (used[bb] < gpb) heap.push(Load(load[bb], bb));   // a full workgroup leaves the heap
             }
         };
-        pass(first_dangling_group, n_groups, dblocks);
-        pass(0, first_dangling_group, B);
+        pass(first_dangling_group, n_groups, dblocks, false);
+        pass(0, first_dangling_group, B, g.hint_blocks == B && G == 1);
         for (uint32_t bb = 0; bb < B; ++bb) ptr[bb + 1] = ptr[bb] + edges[bb];
         return d;
     };
@@ -573,6 +780,25 @@ int lay_out_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned
                         g.fb_val[q] = (uint8_t)src.value_u32(e.h);
                     });
         }
+    }
+    if (getenv("ET_BUILD_STATS")) {
+        // lines of the vector a launch pulls into the L1s: distinct (workgroup, 128-byte line) pairs of the sorted lists
+        auto lines = [&](const std::vector<uint64_t>& ptr, const std::vector<uint32_t>& col, uint32_t B, uint32_t shift, const char* name) {
+            uint64_t total = 0, most = 0, most_e = 0;
+            for (uint32_t b = 0; b < B; ++b) {
+                uint64_t c = 0;
+                for (uint64_t k = ptr[b]; k < ptr[b + 1]; ++k) c += k == ptr[b] || (col[k] >> shift) != (col[k - 1] >> shift);
+                total += c;
+                if (atoi(getenv("ET_BUILD_STATS")) > 1) fprintf(stderr, "[et build wg] %s %u %llu %llu\n", name, b, (unsigned long long)(ptr[b + 1] - ptr[b]), (unsigned long long)c);
+                most = std::max(most, c);
+                most_e = std::max(most_e, ptr[b + 1] - ptr[b]);
+            }
+            fprintf(stderr, "[et build] %s: %u workgroups, %llu edges (most %llu, mean %.1f), %llu line fills (most %llu, mean %.1f), hints %s\n", name, B,
+                    (unsigned long long)ptr[B], (unsigned long long)most_e, (double)ptr[B] / B, (unsigned long long)total, (unsigned long long)most,
+                    (double)total / B, g.hint_blocks == B ? "on" : "off");
+        };
+        lines(g.bk_ptr, g.bk_col, geo.f64_blocks, 4, "f64 sweep");
+        if (geo.fr_blocks) lines(g.fb_ptr, g.fb_col, geo.fr_blocks, 2, "exact sweep");
     }
     if (geo.n_chunks > 1) {
         // a list is sorted by piece: the runs' boundaries by binary search on the piece of an entry's source

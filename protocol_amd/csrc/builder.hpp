@@ -83,6 +83,10 @@ struct HostGraph {
     std::vector<double> scale_f64;      // 1 / integer row sum
     FrRaw inv_nm1_w{};                  // inv(n_valid - 1) * 2^288 mod r
     uint32_t n_dangling_local = 0;      // real dangling rows in this segment
+    // Sources clustered by consumer (cluster_cold_sources): the workgroup each group of active rows is meant for when a
+    // blocked sweep runs hint_blocks workgroups, ~0 = none; empty = positions are in plain degree order
+    std::vector<uint32_t> grp_hint;
+    uint32_t hint_blocks = 0;
 };
 
 // Returns 0 or a negative ET_E_* code; `err` receives a human-readable reason.
