@@ -146,6 +146,17 @@ pub struct et_plan_arrays {
 
 #[repr(C)]
 #[derive(Clone, Copy)]
+pub struct et_sweep_stats {
+    pub blocks: u32,
+    pub clustered: u32,
+    pub edges: u64,
+    pub edges_most: u64,
+    pub line_fills: u64,
+    pub line_fills_most: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
 pub struct et_iter_stats {
     pub sum: et_fr,
     pub changed: u64,
@@ -213,6 +224,7 @@ extern "C" {
     pub fn et_plan_free(p: *mut et_plan);
     pub fn et_plan_info_get(p: *const et_plan, info: *mut et_graph_info) -> c_int;
     pub fn et_plan_arrays_get(p: *const et_plan, out: *mut et_plan_arrays) -> c_int;
+    pub fn et_plan_sweep_stats(p: *const et_plan, variant: c_int, out: *mut et_sweep_stats) -> c_int;
     pub fn et_graph_from_plan(p: *const et_plan, opts: *const et_build_opts, out: *mut *mut et_graph) -> c_int;
     pub fn et_graph_converge_fr(g: *mut et_graph, num_iterations: u32, initial_lo: u64, initial_hi: u64,
                                 out: *mut et_fr) -> c_int;

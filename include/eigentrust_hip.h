@@ -193,6 +193,19 @@ int et_plan_build(uint32_t n, const uint8_t *member, uint64_t n_edges, const uin
 void et_plan_free(et_plan *p);
 int et_plan_info_get(const et_plan *p, et_graph_info *info);   /* device_bytes = 0 */
 int et_plan_arrays_get(const et_plan *p, et_plan_arrays *out);
+/* How a plan's blocked sweep is laid out for one variant (ET_VARIANT_FR or ET_VARIANT_F64).  No counterpart in the
+ * reference (it multiplies one dense matrix, dynamic_sets/native.rs:319-329); for callers that want to see what a launch
+ * will cost before uploading.  line_fills = distinct (workgroup, 128-byte line of the trust vector) pairs of one launch:
+ * the number of lines the compute units pull into their L1s, which is what bounds a sweep.  clustered = 1 when the
+ * positions of peers with few opinions were placed beside the peers the same workgroup gathers (one share, byte
+ * opinions, both variants on the sweep with the same workgroup count; ET_AFFINITY=0 switches it off). */
+typedef struct {
+    uint32_t blocks;          /* workgroups; 0 = this variant does not run the blocked sweep on this plan */
+    uint32_t clustered;
+    uint64_t edges, edges_most;            /* all workgroups, the busiest one */
+    uint64_t line_fills, line_fills_most;
+} et_sweep_stats;
+int et_plan_sweep_stats(const et_plan *p, int variant, et_sweep_stats *out);
 /* Uploads a plan (what et_graph_build does after planning). */
 int et_graph_from_plan(const et_plan *p, const et_build_opts *opts, et_graph **out);
 

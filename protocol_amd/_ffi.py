@@ -76,6 +76,11 @@ class EtPlanArrays(C.Structure):
                 ("n_dangling_pad", C.c_uint32), ("n_dangling_local", C.c_uint32)]
 
 
+class EtSweepStats(C.Structure):
+    _fields_ = [("blocks", C.c_uint32), ("clustered", C.c_uint32), ("edges", C.c_uint64), ("edges_most", C.c_uint64),
+                ("line_fills", C.c_uint64), ("line_fills_most", C.c_uint64)]
+
+
 class EtScore(C.Structure):
     _fields_ = [("address", C.c_uint8 * 20), ("score_fr", C.c_uint8 * 32), ("numerator", C.c_uint8 * 32),
                 ("denominator", C.c_uint8 * 32), ("score", C.c_uint8 * 32)]
@@ -119,6 +124,7 @@ PROTOTYPES = {
     "et_plan_free": (None, [vp]),
     "et_plan_info_get": (i32, [vp, P(EtGraphInfo)]),
     "et_plan_arrays_get": (i32, [vp, P(EtPlanArrays)]),
+    "et_plan_sweep_stats": (i32, [vp, i32, P(EtSweepStats)]),
     "et_graph_from_plan": (i32, [vp, P(EtBuildOpts), P(vp)]),
     "et_graph_free": (None, [vp]),
     "et_graph_info_get": (i32, [vp, P(EtGraphInfo)]),

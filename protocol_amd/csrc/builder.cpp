@@ -1,6 +1,7 @@
 #include "builder.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -276,6 +277,11 @@ int filter_edges(const BuildInput& in, PlanCommon& pc, RowSums& sums, PeerStats&
     return ET_OK;
 }
 
+static double now_s() {
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
 // Step 5b (one share, both variants on the blocked sweep): positions that put a source next to the sources the same
 // workgroup gathers.
 //
@@ -289,6 +295,7 @@ int filter_edges(const BuildInput& in, PlanCommon& pc, RowSums& sums, PeerStats&
 // keep their degree order in front.  Row groups are dealt here (`grp_hint`); lay_out_segment follows the hints where the
 // workgroup has room and levels the rest.  Positions are internal: results are un-permuted by `pos_of_ext` as before.
 static void cluster_cold_sources(PlanCommon& pc, const PeerStats& st, const BuildOpts& opt) {
+    const double t_begin = now_s();
     HostGraph& g = pc.g;
     const Geometry& geo = g.geo;
     const BuildInput& in = pc.in;
@@ -297,7 +304,9 @@ static void cluster_cold_sources(PlanCommon& pc, const PeerStats& st, const Buil
     const uint32_t max_deg = getenv("ET_AFFINITY_MAX_DEG") ? (uint32_t)atoi(getenv("ET_AFFINITY_MAX_DEG")) : 16;
     const uint32_t rounds = getenv("ET_AFFINITY_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("ET_AFFINITY_ROUNDS"))) : 3;
     const uint32_t n_agroups = geo.n_active_pad / BLOCK_GROUP;
-    if (B < 2 || n_agroups / B < 16) return;
+    // below about a thousand rows per workgroup the lines are dense anyway (every workgroup gathers from most of them): measured
+    // gain under 5 % of the fills at 512 rows, for a plan that takes three times as long
+    if (B < 2 || n_agroups / B < 64) return;
     const uint32_t H = n_agroups / B - 3;          // hinted groups per workgroup; the rest is dealt for balance
     const uint32_t NONE = 0xFFFFFFFFu;
     auto by_out = [&](uint32_t a, uint32_t b) {
@@ -314,8 +323,8 @@ static void cluster_cold_sources(PlanCommon& pc, const PeerStats& st, const Buil
         std::nth_element(cold.begin(), cold.begin() + pad, cold.end(), by_out);
         mid.insert(mid.end(), cold.begin(), cold.begin() + pad);
         cold.erase(cold.begin(), cold.begin() + pad);
-        std::sort(cold.begin(), cold.end());
     }
+    std::sort(cold.begin(), cold.end());               // visit order = slot order: the attestation list is walked front to back
     std::sort(mid.begin(), mid.end(), by_out);
     front.insert(front.end(), mid.begin(), mid.end());
     const uint32_t n_front = (uint32_t)front.size(), n_fg = n_front / BLOCK_GROUP, n_cold = (uint32_t)cold.size();
@@ -369,11 +378,13 @@ static void cluster_cold_sources(PlanCommon& pc, const PeerStats& st, const Buil
             }
         }
     }
+    const double t_lp = now_s();
     // ---- label propagation under capacity ----
     // A workgroup's rows and its in-edges must both come out level.  Rows: every workgroup has room for the same number of
-    // hinted groups.  Edges: a workgroup takes a peer only while its edge count stays on the straight line from what the
-    // front's groups gave it to the common target, reached when its room is full (plus a small allowance); a peer nobody
-    // can take that way goes to the workgroup furthest below its line.
+    // hinted groups.  Both fill at the pace of the round: after a fraction of the peers has been visited, a workgroup may
+    // hold that fraction (plus a twentieth) of its room and of the edges between what the front's groups gave it and the
+    // common target.  A popular workgroup therefore stays open to the end of the round, and a peer none of its candidates
+    // takes goes to the emptiest workgroup that does.
     std::vector<uint32_t> rows_cap(B);
     uint64_t cold_room = 0;
     for (uint32_t b = 0; b < B; ++b) { rows_cap[b] = (H - used[b]) * BLOCK_GROUP; cold_room += rows_cap[b]; }
@@ -382,47 +393,71 @@ static void cluster_cold_sources(PlanCommon& pc, const PeerStats& st, const Buil
     for (uint32_t b = 0; b < B; ++b) cost_sum += opt.xcd_cost[b % 8];
     const long double hinted_edges = (long double)front_edges + (long double)cold_edges * cold_room / n_cold;
     const double target = (double)(hinted_edges * ((long double)cost_sum / B) / B), allowance = target * 0.002;
-    std::vector<uint32_t> rows_left(B), votes(B, 0), touched;
-    std::vector<double> load_r(B), slope(B);
-    for (uint32_t b = 0; b < B; ++b) slope[b] = (target - (double)load[b]) / rows_cap[b];
-    auto line = [&](uint32_t b) { return (double)load[b] + slope[b] * (rows_cap[b] - rows_left[b] + 1); };
-    // visit order: a fixed stride through the cold peers, coprime to their number
-    uint64_t stride = (uint64_t)(n_cold * 0.6180339887498949) | 1;
-    while (std::gcd<uint64_t, uint64_t>(stride, n_cold) != 1) stride += 2;
+    std::vector<uint32_t> rows_left(B);
+    std::vector<double> load_r(B);
     const bool stats = getenv("ET_BUILD_STATS") != nullptr;
+    // A round visits the cold peers in SLICES interleaved slices.  Inside a slice the votes are counted on all host threads
+    // from the labels as they stand (the earlier slices of this round included), the three best labels per peer are kept,
+    // and the peers are then placed one after the other under the capacities: the outcome does not depend on the thread count.
+    const uint32_t SLICES = 8, KEEP = 8;
+    const unsigned T = host_threads();
+    std::vector<uint32_t> cand((size_t)n_cold * KEEP, NONE);
+    auto mix = [](uint32_t f, uint32_t l) { uint64_t z = ((uint64_t)f << 20 ^ l) * 0x9E3779B97F4A7C15ull; return z ^ (z >> 29); };
     for (uint32_t round = 0; round < rounds; ++round) {
         rows_left = rows_cap;
         for (uint32_t b = 0; b < B; ++b) load_r[b] = (double)load[b];
         uint64_t by_vote = 0, moved = 0;
-        for (uint32_t step = 0; step < n_cold; ++step) {
-            const uint32_t k = (uint32_t)(((uint64_t)step * stride) % n_cold), f = cold[k];
-            touched.clear();
-            auto vote = [&](uint32_t ext) {
-                const uint32_t l = label[ext];       // this round's label if the peer was visited already, else the last round's
-                if (l == NONE) return;
-                if (votes[l]++ == 0) touched.push_back(l);
-            };
-            for (uint64_t e = pc.out_ptr[f]; e < pc.out_ptr[f + 1]; ++e) if (!pc.drop[e]) vote(in.to[pc.kept[e]]);
-            for (uint64_t e = rin_ptr[k]; e < rin_ptr[k + 1]; ++e) vote(rin[e]);
-            uint32_t best = NONE;
-            for (uint32_t l : touched) {
-                if (rows_left[l] && load_r[l] + (double)st.in_deg[f] * opt.xcd_cost[l % 8] <= line(l) + allowance &&
-                    (best == NONE || votes[l] > votes[best] || (votes[l] == votes[best] && rows_left[l] > rows_left[best])))
-                    best = l;
-            }
-            for (uint32_t l : touched) votes[l] = 0;
-            by_vote += best != NONE;
-            if (best == NONE) {
-                double worst = 0;
-                for (uint32_t b = 0; b < B; ++b) {
-                    if (!rows_left[b]) continue;
-                    const double behind = line(b) - load_r[b];
-                    if (best == NONE || behind > worst) { best = b; worst = behind; }
+        uint32_t visited = 0;
+        for (uint32_t sl = 0; sl < SLICES; ++sl) {
+            const uint32_t members = n_cold > sl ? (n_cold - sl + SLICES - 1) / SLICES : 0;
+            run_threads(T, [&](unsigned t) {
+                std::vector<uint32_t> votes(B, 0), touched;
+                for (uint32_t j = (uint32_t)((uint64_t)members * t / T); j < (uint32_t)((uint64_t)members * (t + 1) / T); ++j) {
+                    const uint32_t k = sl + SLICES * j, f = cold[k];
+                    touched.clear();
+                    auto vote = [&](uint32_t ext) {
+                        const uint32_t l = label[ext];
+                        if (l == NONE) return;
+                        if (votes[l]++ == 0) touched.push_back(l);
+                    };
+                    for (uint64_t e = pc.out_ptr[f]; e < pc.out_ptr[f + 1]; ++e) if (!pc.drop[e]) vote(in.to[pc.kept[e]]);
+                    for (uint64_t e = rin_ptr[k]; e < rin_ptr[k + 1]; ++e) vote(rin[e]);
+                    for (uint32_t c = 0; c < KEEP; ++c) {
+                        uint32_t best = NONE, at = 0;
+                        for (uint32_t i = 0; i < touched.size(); ++i) {
+                            const uint32_t l = touched[i];
+                            if (votes[l] && (best == NONE || votes[l] > votes[best] || (votes[l] == votes[best] && mix(f, l) < mix(f, best)))) { best = l; at = i; }
+                        }
+                        cand[(size_t)k * KEEP + c] = best;
+                        if (best != NONE) { votes[best] = 0; touched[at] = touched.back(); touched.pop_back(); }
+                    }
+                    for (uint32_t l : touched) votes[l] = 0;
                 }
+            });
+            for (uint32_t j = 0; j < members; ++j, ++visited) {
+                const uint32_t k = sl + SLICES * j, f = cold[k];
+                // how far a workgroup may have filled by now: the round's progress plus a twentieth, in rows and in edges
+                const double pace = std::min(1.0, (double)(visited + 1) / n_cold * 1.05);
+                auto takes = [&](uint32_t b) {
+                    return rows_left[b] && (double)(rows_cap[b] - rows_left[b]) < pace * rows_cap[b] + 16.0 &&
+                           load_r[b] + (double)st.in_deg[f] * opt.xcd_cost[b % 8] <= (double)load[b] + (target - (double)load[b]) * pace + allowance;
+                };
+                uint32_t best = NONE;
+                for (uint32_t c = 0; c < KEEP && best == NONE; ++c) {
+                    const uint32_t l = cand[(size_t)k * KEEP + c];
+                    if (l == NONE) break;
+                    if (takes(l)) best = l;
+                }
+                by_vote += best != NONE;
+                if (best == NONE) {
+                    // the emptiest workgroup that takes the peer; if none does the peer stays without one and is dealt for balance
+                    for (uint32_t b = 0; b < B; ++b)
+                        if (takes(b) && (best == NONE || (uint64_t)rows_left[b] * rows_cap[best] > (uint64_t)rows_left[best] * rows_cap[b])) best = b;
+                }
+                moved += label[f] != best;
+                label[f] = best;
+                if (best != NONE) { --rows_left[best]; load_r[best] += (double)st.in_deg[f] * opt.xcd_cost[best % 8]; }
             }
-            moved += label[f] != best;
-            label[f] = best;
-            if (best != NONE) { --rows_left[best]; load_r[best] += (double)st.in_deg[f] * opt.xcd_cost[best % 8]; }
         }
         if (stats) {
             uint64_t local = 0, all = 0;
@@ -436,9 +471,12 @@ static void cluster_cold_sources(PlanCommon& pc, const PeerStats& st, const Buil
                     round, n_cold, n_active, (unsigned long long)by_vote, (unsigned long long)moved, (unsigned long long)local, (unsigned long long)all, lo, hi, target);
         }
     }
+    const double t_order = now_s();
     // ---- order: front, then workgroup by workgroup, inside by the workgroup of another rated peer; then the rest ----
     std::vector<uint64_t> key(n_cold);
-    for (uint32_t k = 0; k < n_cold; ++k) {
+    run_threads(T, [&](unsigned t) {
+      std::vector<uint32_t> votes(B, 0), touched;
+      for (uint32_t k = (uint32_t)((uint64_t)n_cold * t / T); k < (uint32_t)((uint64_t)n_cold * (t + 1) / T); ++k) {
         const uint32_t f = cold[k], own = label[f];
         touched.clear();
         for (uint64_t e = pc.out_ptr[f]; e < pc.out_ptr[f + 1]; ++e) {
@@ -449,23 +487,36 @@ static void cluster_cold_sources(PlanCommon& pc, const PeerStats& st, const Buil
         }
         uint32_t second = B;
         // ties are broken by a hash of (peer, workgroup): every workgroup gets its share of the second-level runs
-        auto mix = [&](uint32_t l) { uint64_t z = ((uint64_t)f << 20 ^ l) * 0x9E3779B97F4A7C15ull; return z ^ (z >> 29); };
-        for (uint32_t l : touched) if (second == B || votes[l] > votes[second] || (votes[l] == votes[second] && mix(l) < mix(second))) second = l;
+        for (uint32_t l : touched) if (second == B || votes[l] > votes[second] || (votes[l] == votes[second] && mix(f, l) < mix(f, second))) second = l;
         for (uint32_t l : touched) votes[l] = 0;
         key[k] = ((uint64_t)(own == NONE ? B : own) << 32) | second;
-    }
+      }
+    });
     std::vector<uint32_t> by_key(n_cold);
     std::iota(by_key.begin(), by_key.end(), 0u);
     std::sort(by_key.begin(), by_key.end(), [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] < key[b] : cold[a] < cold[b]; });
     for (uint32_t r = 0; r < n_front; ++r) order[r] = front[r];
-    for (uint32_t k = 0; k < n_cold; ++k) {
-        const uint32_t r = n_front + k, own = (uint32_t)(key[by_key[k]] >> 32);
-        order[r] = cold[by_key[k]];
-        if (own < B) hint[r / BLOCK_GROUP] = own;    // a workgroup's peers fill whole groups: its room is a multiple of the group
+    {
+        // a workgroup's peers fill whole groups; the few beyond its last whole group join the peers without a workgroup, which
+        // follow in order of in-degree: groups of like weight, the light ones left for the workgroups that are heavy already
+        std::vector<uint32_t> rest;
+        uint32_t r = n_front, k = 0;
+        while (k < n_cold) {
+            const uint32_t own = (uint32_t)(key[by_key[k]] >> 32);
+            uint32_t k1 = k;
+            while (k1 < n_cold && (uint32_t)(key[by_key[k1]] >> 32) == own) ++k1;
+            const uint32_t whole = own < B ? (k1 - k) / BLOCK_GROUP * BLOCK_GROUP : 0;
+            for (uint32_t i = k; i < k + whole; ++i, ++r) { order[r] = cold[by_key[i]]; hint[r / BLOCK_GROUP] = own; }
+            for (uint32_t i = k + whole; i < k1; ++i) rest.push_back(cold[by_key[i]]);
+            k = k1;
+        }
+        std::sort(rest.begin(), rest.end(), [&](uint32_t a, uint32_t b) { return st.in_deg[a] != st.in_deg[b] ? st.in_deg[a] > st.in_deg[b] : a < b; });
+        for (uint32_t i : rest) order[r++] = i;
     }
     for (uint32_t r = 0; r < n_active; ++r) g.pos_of_ext[order[r]] = r;     // one share: position = rank
     g.grp_hint.swap(hint);
     g.hint_blocks = B;
+    if (stats) fprintf(stderr, "[et build] clustering: classes and raters %.2f s, label propagation %.2f s, order %.2f s\n", t_lp - t_begin, t_order - t_lp, now_s() - t_order);
 }
 
 int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& pc, std::string& err) {
@@ -782,23 +833,13 @@ int lay_out_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned
         }
     }
     if (getenv("ET_BUILD_STATS")) {
-        // lines of the vector a launch pulls into the L1s: distinct (workgroup, 128-byte line) pairs of the sorted lists
-        auto lines = [&](const std::vector<uint64_t>& ptr, const std::vector<uint32_t>& col, uint32_t B, uint32_t shift, const char* name) {
-            uint64_t total = 0, most = 0, most_e = 0;
-            for (uint32_t b = 0; b < B; ++b) {
-                uint64_t c = 0;
-                for (uint64_t k = ptr[b]; k < ptr[b + 1]; ++k) c += k == ptr[b] || (col[k] >> shift) != (col[k - 1] >> shift);
-                total += c;
-                if (atoi(getenv("ET_BUILD_STATS")) > 1) fprintf(stderr, "[et build wg] %s %u %llu %llu\n", name, b, (unsigned long long)(ptr[b + 1] - ptr[b]), (unsigned long long)c);
-                most = std::max(most, c);
-                most_e = std::max(most_e, ptr[b + 1] - ptr[b]);
-            }
-            fprintf(stderr, "[et build] %s: %u workgroups, %llu edges (most %llu, mean %.1f), %llu line fills (most %llu, mean %.1f), hints %s\n", name, B,
-                    (unsigned long long)ptr[B], (unsigned long long)most_e, (double)ptr[B] / B, (unsigned long long)total, (unsigned long long)most,
-                    (double)total / B, g.hint_blocks == B ? "on" : "off");
-        };
-        lines(g.bk_ptr, g.bk_col, geo.f64_blocks, 4, "f64 sweep");
-        if (geo.fr_blocks) lines(g.fb_ptr, g.fb_col, geo.fr_blocks, 2, "exact sweep");
+        for (int exact = 0; exact < 2; ++exact) {
+            const SweepStats ss = sweep_stats(g, exact != 0);
+            if (ss.blocks)
+                fprintf(stderr, "[et build] %s sweep: %u workgroups, %llu edges (most %llu, mean %.1f), %llu line fills (most %llu, mean %.1f), clustered %u\n",
+                        exact ? "exact" : "f64", ss.blocks, (unsigned long long)ss.edges, (unsigned long long)ss.edges_most, (double)ss.edges / ss.blocks,
+                        (unsigned long long)ss.line_fills, (unsigned long long)ss.line_fills_most, (double)ss.line_fills / ss.blocks, ss.clustered);
+        }
     }
     if (geo.n_chunks > 1) {
         // a list is sorted by piece: the runs' boundaries by binary search on the piece of an entry's source
@@ -939,6 +980,25 @@ int lay_out_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned
 }
 
 }  // namespace
+
+SweepStats sweep_stats(const HostGraph& g, bool exact) {
+    SweepStats ss;
+    const std::vector<uint64_t>& ptr = exact ? g.fb_ptr : g.bk_ptr;
+    const std::vector<uint32_t>& col = exact ? g.fb_col : g.bk_col;
+    const uint32_t B = exact ? g.geo.fr_blocks : g.geo.f64_blocks, shift = exact ? 2 : 4;
+    if (B == 0 || ptr.size() != (size_t)B + 1 || col.size() < ptr[B]) return ss;
+    ss.blocks = B;
+    ss.clustered = g.hint_blocks == B && !g.grp_hint.empty();
+    ss.edges = ptr[B];
+    for (uint32_t b = 0; b < B; ++b) {
+        uint64_t c = 0;
+        for (uint64_t k = ptr[b]; k < ptr[b + 1]; ++k) c += k == ptr[b] || (col[k] >> shift) != (col[k - 1] >> shift);
+        ss.line_fills += c;
+        ss.line_fills_most = std::max(ss.line_fills_most, c);
+        ss.edges_most = std::max(ss.edges_most, ptr[b + 1] - ptr[b]);
+    }
+    return ss;
+}
 
 int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index, HostGraph& g, std::string& err) {
     if (seg_index >= pc.g.geo.n_seg) { err = "bad segment"; return ET_E_INVALID_ARG; }

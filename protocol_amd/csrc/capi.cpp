@@ -152,6 +152,14 @@ int et_plan_arrays_get(const et_plan* p, et_plan_arrays* out) {
     out->n_dangling_pad = h.geo.n_dangling_pad; out->n_dangling_local = h.n_dangling_local;
     return ET_OK;
 }
+int et_plan_sweep_stats(const et_plan* p, int variant, et_sweep_stats* out) {
+    if (!p || !out || (variant != ET_VARIANT_FR && variant != ET_VARIANT_F64)) return ET_E_INVALID_ARG;
+    const SweepStats ss = sweep_stats(p->h, variant == ET_VARIANT_FR);
+    out->blocks = ss.blocks; out->clustered = ss.clustered;
+    out->edges = ss.edges; out->edges_most = ss.edges_most;
+    out->line_fills = ss.line_fills; out->line_fills_most = ss.line_fills_most;
+    return ET_OK;
+}
 int et_graph_from_plan(const et_plan* p, const et_build_opts* opts, et_graph** out) {
     if (!p || !out) return ET_E_INVALID_ARG;
     DeviceGraph* dg = nullptr;

@@ -360,6 +360,12 @@ class Plan:
             check(lib().et_plan_arrays_get(h, C.byref(arr)))
             self.info = info
             self.n = n
+            # layout of the blocked sweeps: workgroups, edges and 128-byte lines of the vector a launch pulls in
+            self.sweep = {}
+            for name, variant in (("fr", _ffi.ET_VARIANT_FR), ("f64", _ffi.ET_VARIANT_F64)):
+                ss = _ffi.EtSweepStats()
+                check(lib().et_plan_sweep_stats(h, variant, C.byref(ss)))
+                self.sweep[name] = {f: int(getattr(ss, f)) for f, _ in _ffi.EtSweepStats._fields_}
             slots = int(info.padded_local)
             vec_len = int(info.vec_len)
             self.pos_of_slot = np.ctypeslib.as_array(arr.pos_of_slot, (n,)).copy()

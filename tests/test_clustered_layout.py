@@ -1,0 +1,88 @@
+"""Positions clustered by consumer (cluster_cold_sources in csrc/builder.cpp): the plan of a graph large enough for it
+must still be a permutation of the peers, keep the workgroups' edge counts level, and pull fewer 128-byte lines of the
+trust vector per launch than the plain degree order.  CPU only: et_plan_build needs no GPU."""
+import numpy as np
+import pytest
+
+import protocol_amd as pa
+
+N, M = 1 << 19, 1 << 23          # 2048 rows per workgroup of a 256-workgroup sweep
+
+
+@pytest.fixture(scope="module")
+def graph():
+    return pa.synth_graph(3, N, M, seed=11, value_max=255)
+
+
+def _plan(graph, monkeypatch, affinity):
+    frm, to, val = graph
+    monkeypatch.setenv("ET_AFFINITY", "1" if affinity else "0")
+    return pa.Plan(N, frm, to, value_u32=val)
+
+
+def test_clustered_positions_are_a_permutation_with_level_workgroups_and_fewer_line_fills(graph, monkeypatch):
+    plain = _plan(graph, monkeypatch, False)
+    clustered = _plan(graph, monkeypatch, True)
+    for variant in ("f64", "fr"):
+        a, b = plain.sweep[variant], clustered.sweep[variant]
+        assert a["blocks"] == b["blocks"] == 256
+        assert a["clustered"] == 0 and b["clustered"] == 1
+        assert a["edges"] == b["edges"] == int(plain.info.nnz)
+        # a launch ends with its slowest workgroup: the deal must stay level
+        assert b["edges_most"] <= 1.01 * b["edges"] / 256
+        # fewer lines, for the busiest workgroup as for all of them
+        assert b["line_fills"] < 0.92 * a["line_fills"], (variant, a, b)
+        assert b["line_fills_most"] < 0.94 * a["line_fills_most"], (variant, a, b)
+    # the same peers hold the same set of positions; only who sits where changes
+    pa_, pb = plain.pos_of_slot, clustered.pos_of_slot
+    assert np.array_equal(np.sort(pa_), np.sort(pb))
+    members = pb != 0xFFFFFFFF
+    assert len(np.unique(pb[members])) == int(members.sum()) == int(plain.info.n_valid)
+    assert not np.array_equal(pa_, pb)
+    # factors travel with the peers: the factor at a peer's position is the same number in both plans
+    assert np.array_equal(plain.scale_f64[pa_[members]], clustered.scale_f64[pb[members]])
+
+
+def test_small_graphs_and_several_shares_keep_the_degree_order(monkeypatch):
+    frm, to, val = pa.synth_graph(3, 1 << 15, 1 << 19, seed=3, value_max=255)
+    monkeypatch.setenv("ET_AFFINITY", "1")
+    small = pa.Plan(1 << 15, frm, to, value_u32=val)
+    assert small.sweep["f64"]["clustered"] == 0 and small.sweep["fr"]["clustered"] == 0
+    frm, to, val = pa.synth_graph(3, 1 << 19, 1 << 22, seed=3, value_max=255)
+    share = pa.Plan(1 << 19, frm, to, value_u32=val, n_seg=2, seg=1)
+    assert share.sweep["f64"]["clustered"] == 0
+
+
+@pytest.mark.gpu
+def test_clustered_and_plain_positions_give_the_same_scores_on_the_gpu(monkeypatch):
+    """Positions are internal: with the peers clustered by consumer or in plain degree order the exact variant returns
+    the same bits (and the CPU checker's), the f64 variant the same scores to 1e-9 relative L1.  Empty slots, peers
+    without opinions and repeated attestation pairs included."""
+    import c_oracle
+
+    n, m = 1 << 19, 1 << 23
+    frm, to, val = pa.synth_graph(3, n, m, seed=5, value_max=255)
+    rng = np.random.default_rng(5)
+    member = (rng.random(n) > 0.02).astype(np.uint8)
+    dup = rng.integers(0, len(frm), size=50000)          # later attestations for the same pair replace earlier ones
+    frm = np.concatenate([frm, frm[dup]])
+    to = np.concatenate([to, to[dup]])
+    val = np.concatenate([val, rng.integers(0, 256, size=len(dup)).astype(np.uint32)])
+    rc, exp, nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=20, initial=1000,
+                                                  n_threads=c_oracle.max_threads())
+    assert rc == 0
+    rc, _e, eld, _r, _, _ = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=20, initial=1000.0,
+                                                         n_threads=c_oracle.max_threads(), want_ld=True)
+    assert rc == 0
+    outs = {}
+    for affinity in ("0", "1"):
+        monkeypatch.setenv("ET_AFFINITY", affinity)
+        g = pa.Graph(n, frm, to, value_u32=val, member=member)
+        assert g.info.nnz == nnz
+        outs[affinity] = (g.converge_fr(20, 1000), g.converge_f64(20, 1000.0)[0])
+        g.close()
+    assert np.array_equal(outs["0"][0], exp)
+    assert np.array_equal(outs["1"][0], exp)
+    for affinity in ("0", "1"):
+        a = np.asarray(outs[affinity][1], dtype=np.longdouble)
+        assert float(np.abs(a - eld).sum() / np.abs(eld).sum()) <= 1e-9
