@@ -136,6 +136,7 @@ int layout_common(uint32_t n, const uint8_t* member, bool values_are_u32, const 
     auto q_of_rank = [&](uint32_t r) { return r < n_active ? r : geo.n_active_pad + (r - n_active); };
     g.pos_of_ext.assign(n, 0xFFFFFFFFu);
     for (uint32_t r = 0; r < n_valid; ++r) g.pos_of_ext[order[r]] = P.pos_of(q_of_rank(r));
+    g.dense_prefix = G == 1 ? std::min<uint32_t>(n_active, opt.hot_prefix) : 0u;
 
     return ET_OK;
 }
@@ -516,6 +517,7 @@ static void cluster_cold_sources(PlanCommon& pc, const PeerStats& st, const Buil
     for (uint32_t r = 0; r < n_active; ++r) g.pos_of_ext[order[r]] = r;     // one share: position = rank
     g.grp_hint.swap(hint);
     g.hint_blocks = B;
+    g.dense_prefix = n_front;
     if (stats) fprintf(stderr, "[et build] clustering: classes and raters %.2f s, label propagation %.2f s, order %.2f s\n", t_lp - t_begin, t_order - t_lp, now_s() - t_order);
 }
 

@@ -87,6 +87,10 @@ struct HostGraph {
     // blocked sweep runs hint_blocks workgroups, ~0 = none; empty = positions are in plain degree order
     std::vector<uint32_t> grp_hint;
     uint32_t hint_blocks = 0;
+    // One share: the leading positions held by the most-attesting peers in order of out-degree (the hot prefix; with clustered
+    // positions every peer above the clustering threshold).  A sweep's edges from these sources come first in every
+    // workgroup's list and read a dense, cache-resident part of the vector.  0 = not known (several shares).
+    uint32_t dense_prefix = 0;
 };
 
 // Returns 0 or a negative ET_E_* code; `err` receives a human-readable reason.

@@ -174,6 +174,8 @@ struct StepArgsF64B {
     const uint64_t* phase_ptr;
     double* acc_g;
     uint32_t phase, n_phases;
+    uint32_t bar_period;      // batches between two barriers of the sweep
+    uint32_t bar_first_256;   // the first one after this many 256ths of the workgroup's batches
 };
 
 // PHASED: one of several launches of an iteration (chunked exchange); otherwise the launch is the whole iteration and
@@ -243,6 +245,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     // second batch keeps all sixteen within one window of the source range.
     const uint32_t n_batches = (uint32_t)((e1 - e0) / (U * 1024));
     uint64_t e = e0 + threadIdx.x;
+    int since_bar = (int)a.bar_period - (int)max(a.bar_period, (n_batches * a.bar_first_256) >> 8);
     if (PACKED) {
         const uint32_t* __restrict__ cb = a.cbase + a.cptr[b];
         uint32_t chunk = wave;                             // (e - e0) / 64
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
             for (int u = 0; u < U; ++u) xv[u] = xr[(size_t)base[u] + (rc[u] >> 16)];
 #pragma unroll
             for (int u = 0; u < U; ++u) atomicAdd(&acc_l[rc[u] & 0xFFFFu], w[u] * xv[u]);
-            if (k & 1) __syncthreads();
+            if (++since_bar == (int)a.bar_period) { since_bar = 0; __syncthreads(); }
         }
         {   // the rest of the list (fewer than U * 1024 edges) as one more batch, its loads in flight together like the
             // others': taken 1024 at a time it was up to three more trips to memory, one after the other
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
             for (int u = 0; u < U; ++u) xv[u] = xr[(size_t)(c[u] >> COL_SEG_SHIFT) * stride + (c[u] & COL_LOCAL_MASK)];
 #pragma unroll
             for (int u = 0; u < U; ++u) atomicAdd(&acc_l[r[u]], w[u] * xv[u]);
-            if (k & 1) __syncthreads();
+            if (++since_bar == (int)a.bar_period) { since_bar = 0; __syncthreads(); }
         }
         {   // the rest of the list as one more batch (see the packed form above)
             uint32_t c[U], r[U];
@@ -727,6 +730,8 @@ struct StepArgsFrB {
     uint32_t phase, n_phases;
     U256 inv_nm1_w;
     U256 inv_nm1_w576;        // inv(n_valid - 1) * 2^576
+    uint32_t bar_period;      // passes between two barriers of the sweep
+    uint32_t bar_first_256;   // the first one after this many 256ths of the workgroup's passes
 };
 
 __global__ void k_scale_288(const uint4* __restrict__ scale576, uint4* __restrict__ scale288, size_t n) {
@@ -794,9 +799,9 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     // Asking for the next element's halves before this element's adds (two in flight again) costs 6 us, non-temporal
     // record loads 17 us.
     constexpr int U = 1;
-    constexpr int BAR = 8;
     const uint32_t n_batches = (uint32_t)((e1 - e0) / (U * 1024));
     uint64_t e = e0 + threadIdx.x;
+    int since_bar = (int)a.bar_period - (int)max(a.bar_period, (n_batches * a.bar_first_256) >> 8);
     // a carry into word k of a row (k = 1..3), or into the top limb (k = 4)
     auto carry_into = [&](uint32_t slot, uint32_t k) {
         for (; k < 4; ++k)
@@ -880,7 +885,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             for (int u = 0; u < U; ++u) fetch(en + u * 1024, cn[u], vn[u], rn[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) add_edge(r[u], v[u], lo[u], hi[u]);
-            if (k % BAR == BAR - 1) __syncthreads();
+            if (++since_bar == (int)a.bar_period) { since_bar = 0; __syncthreads(); }
 #pragma unroll
             for (int u = 0; u < U; ++u) { c[u] = cn[u]; v[u] = vn[u]; r[u] = rn[u]; }
         }
@@ -1229,6 +1234,35 @@ void xcd_cost_factors(int device, uint32_t out[8]) {
         fprintf(stderr, "xcd cost factors (device %d): %u %u %u %u %u %u %u %u\n", device, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
 }
 
+// Where a sweep's barriers start.  The barriers hold the sixteen wavefronts of a workgroup inside one window of the vector
+// so that the window is shared through the L2; over the leading, densely gathered positions (the most-attesting peers, a
+// megabyte or so that stays cached whatever the wavefronts do) they only cost: every barrier waits for the slowest
+// wavefront.  So on one share the first barrier comes where the workgroups' lists leave that prefix, if the prefix carries a
+// quarter of the edges or more; the exact sweep then takes a barrier every fourth pass instead of every eighth.  1M peers /
+// 16M edges, power-law out-degrees: f64 45.5 -> 43 us, exact 106.4 -> 102 us; a uniform graph of the same size has no such
+// prefix and loses 2 us (f64) and 20 us (exact) if made to wait, a share of a 16M-peer graph 18 us.
+// ET_F64_BARRIER / ET_FR_BARRIER (period) and ET_F64_BARRIER_FROM / ET_FR_BARRIER_FROM (percent of the list) override.
+static void sweep_barriers(const HostGraph& h, DeviceGraph& g) {
+    auto dense_share_256 = [&](const std::vector<uint64_t>& ptr, const std::vector<uint32_t>& col, uint32_t B) -> uint32_t {
+        if (h.geo.n_seg != 1 || h.geo.n_chunks != 1 || h.dense_prefix == 0 || B == 0 || ptr.size() != (size_t)B + 1 || ptr[B] == 0) return 0;
+        uint64_t dense = 0;
+        for (uint32_t b = 0; b < B; ++b)      // a list ascends by position; one share: the source code is the position
+            dense += std::partition_point(col.begin() + ptr[b], col.begin() + ptr[b + 1], [&](uint32_t c) { return c < h.dense_prefix; }) - (col.begin() + ptr[b]);
+        return (uint32_t)(dense * 256 / ptr[B]);
+    };
+    auto env_int = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; };
+    uint32_t share = dense_share_256(h.bk_ptr, h.bk_col, h.geo.f64_blocks);
+    g.f64_bar_period = 2; g.f64_bar_first_256 = share >= 64 ? std::min(share, 230u) : 0u;
+    share = dense_share_256(h.fb_ptr, h.fb_col, h.geo.fr_blocks);
+    g.fr_bar_first_256 = share >= 64 ? std::min(share, 230u) : 0u;
+    g.fr_bar_period = g.fr_bar_first_256 ? 4 : 8;
+    if (env_int("ET_F64_BARRIER") > 0) g.f64_bar_period = (uint32_t)env_int("ET_F64_BARRIER");
+    if (env_int("ET_F64_BARRIER_FROM") >= 0) g.f64_bar_first_256 = (uint32_t)env_int("ET_F64_BARRIER_FROM") * 256 / 100;
+    if (env_int("ET_FR_BARRIER") > 0) g.fr_bar_period = (uint32_t)env_int("ET_FR_BARRIER");
+    if (env_int("ET_FR_BARRIER_FROM") >= 0) g.fr_bar_first_256 = (uint32_t)env_int("ET_FR_BARRIER_FROM") * 256 / 100;
+    if (getenv("ET_BUILD_STATS")) fprintf(stderr, "[et upload] barriers: f64 every %u from %u/256, exact every %u from %u/256\n", g.f64_bar_period, g.f64_bar_first_256, g.fr_bar_period, g.fr_bar_first_256);
+}
+
 int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGraph** out) {
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -1256,6 +1290,7 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     const size_t slots = (size_t)h.n_steps * 64;
     const size_t vec_len = (size_t)h.geo.n_seg * h.geo.seg_stride();
     g->vec_len = vec_len;
+    sweep_barriers(h, *g);
     // raw form: opinions stay as they are (one byte each when they fit), the source factors stay
     // resident; weighted form: opinions and factors are only needed until the weights are computed
     g->raw = h.values_are_u32;
@@ -1426,6 +1461,7 @@ int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double
     a.res_part = d_res_part + ring; a.sum_part = d_sum_part + ring;
     a.geo = geo; a.inv_nm1 = inv_nm1; a.alpha = alpha; a.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u;
     a.phase_ptr = d_bk_phase; a.acc_g = d_f64_acc; a.n_phases = geo.n_chunks;
+    a.bar_period = f64_bar_period; a.bar_first_256 = f64_bar_first_256;
     if (phase >= (int)geo.n_chunks) { set_error("no such phase"); return ET_E_OUT_OF_RANGE; }
     const size_t lds = (size_t)geo.f64_rb * sizeof(double);
     // phase < 0: the whole iteration, as n_chunks launches one after the other
@@ -1455,6 +1491,7 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
         fb.geo = geo; fb.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u; fb.inv_nm1_w = to_u256(inv_nm1_w);
         fb.inv_nm1_w576 = to_u256((Fr::from_raw(inv_nm1_w) * Fr::one().pow2k(288)).to_raw());
         fb.phase_ptr = d_fb_phase; fb.acc_g = d_fr_acc; fb.n_phases = geo.n_chunks;
+        fb.bar_period = fr_bar_period; fb.bar_first_256 = fr_bar_first_256;
         if (phase >= (int)geo.n_chunks) { set_error("no such phase"); return ET_E_OUT_OF_RANGE; }
         for (uint32_t q = phase < 0 ? 0u : (uint32_t)phase; q < (phase < 0 ? geo.n_chunks : (uint32_t)phase + 1); ++q) {
             fb.phase = q;

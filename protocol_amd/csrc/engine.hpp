@@ -56,6 +56,8 @@ struct DeviceGraph {
     void* d_bk_w = nullptr;
     // byte opinions: d_bk_col / d_bk_row replaced by packed records (slot | source offset << 16) plus one base
     // position per 64 edges
+    // where the sweeps' barriers start and how often they come (see sweep_barriers in engine.hip)
+    uint32_t f64_bar_period = 2, f64_bar_first_256 = 0, fr_bar_period = 8, fr_bar_first_256 = 0;
     bool packed = false;
     uint32_t* d_bk_rec = nullptr;
     uint32_t* d_bk_cbase = nullptr;
