@@ -86,3 +86,13 @@ def test_clustered_and_plain_positions_give_the_same_scores_on_the_gpu(monkeypat
     for affinity in ("0", "1"):
         a = np.asarray(outs[affinity][1], dtype=np.longdouble)
         assert float(np.abs(a - eld).sum() / np.abs(eld).sum()) <= 1e-9
+
+
+def test_the_clustered_plan_does_not_depend_on_the_number_of_host_threads(graph, monkeypatch):
+    """Votes are counted on all host threads, placement is sequential: one thread or many give the same positions."""
+    monkeypatch.setenv("ET_BUILD_THREADS", "1")
+    one = _plan(graph, monkeypatch, True)
+    monkeypatch.setenv("ET_BUILD_THREADS", "7")
+    many = _plan(graph, monkeypatch, True)
+    assert np.array_equal(one.pos_of_slot, many.pos_of_slot)
+    assert one.sweep == many.sweep
