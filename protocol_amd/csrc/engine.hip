@@ -92,6 +92,10 @@ ET_DEV bool row_is_member(const Geometry& g, uint32_t local) {
     uint64_t q = ((uint64_t)(local >> 6) * g.n_seg + g.seg) * 64 + (local & 63);
     return q < g.n_active || (q >= g.n_active_pad && q < (uint64_t)g.n_active_pad + g.n_dangling);
 }
+ET_DEV bool row_is_dangling(const Geometry& g, uint32_t local) {
+    uint64_t q = ((uint64_t)(local >> 6) * g.n_seg + g.seg) * 64 + (local & 63);
+    return q >= g.n_active_pad && q < (uint64_t)g.n_active_pad + g.n_dangling;
+}
 __global__ void k_init_f64(Geometry g, double initial, double d0, double* __restrict__ x,
                            double* __restrict__ own, const double* __restrict__ scale) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -160,7 +164,7 @@ struct StepArgsF64B {
     const uint16_t* row;
     const double* x;
     double* y;
-    double* own;              // raw form: plain scores of this segment's rows, updated in place
+    double* own;              // raw form: plain scores of this segment's dangling rows (factor zero), updated in place
     const double* scale;      // raw form: 1 / row sum by position
     const double* pretrust;
     double* res_part;   // [f64_blocks]
@@ -230,8 +234,10 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
         const uint32_t row = pgrp[u] * BLOCK_GROUP + lr % BLOCK_GROUP;
         pold[u] = psc[u] = ppt[u] = 0.0;
         if (pgrp[u] != 0xFFFFFFFFu) {                      // rows beyond the members read a valid address and are dropped later
-            pold[u] = RAW ? a.own[row] : xr[my_base + row];
-            if (RAW && !a.final_step) psc[u] = a.scale[my_base + row];
+            // raw form: a peer with opinions keeps no plain score between iterations (its old one is the exchanged entry
+            // divided by the factor); a peer without has factor zero and keeps its plain score in `own`
+            pold[u] = RAW && row_is_dangling(a.geo, row) ? a.own[row] : xr[my_base + row];
+            if (RAW) psc[u] = a.scale[my_base + row];
             if (HAS_ALPHA) ppt[u] = a.pretrust[my_base + row];
         }
     }
@@ -346,10 +352,11 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
             if (first) {
                 if (live[u]) { old[u] = pold[u]; sc[u] = psc[u]; pt[u] = ppt[u]; }
             } else if (live[u]) {
-                old[u] = RAW ? a.own[row[u]] : xr[my_base + row[u]];
-                if (RAW && !a.final_step) sc[u] = a.scale[my_base + row[u]];
+                old[u] = RAW && dang[u] ? a.own[row[u]] : xr[my_base + row[u]];
+                if (RAW) sc[u] = a.scale[my_base + row[u]];
                 if (HAS_ALPHA) pt[u] = a.pretrust[my_base + row[u]];
             }
+            if (RAW && live[u] && !dang[u]) old[u] = old[u] / sc[u];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
             double v = dang[u] ? s + (D - old[u]) * a.inv_nm1 : s + dterm;
             if (HAS_ALPHA) v = (1.0 - a.alpha) * v + a.alpha * pt[u];
             if (RAW) {
-                a.own[row[u]] = v;
+                if (dang[u]) a.own[row[u]] = v;
                 a.y[my_base + row[u]] = a.final_step ? v : v * sc[u];
             } else {
                 a.y[my_base + row[u]] = v;
