@@ -400,7 +400,7 @@ static void cluster_cold_sources(PlanCommon& pc, const PeerStats& st, const Buil
     // A round visits the cold peers in SLICES interleaved slices.  Inside a slice the votes are counted on all host threads
     // from the labels as they stand (the earlier slices of this round included), the three best labels per peer are kept,
     // and the peers are then placed one after the other under the capacities: the outcome does not depend on the thread count.
-    const uint32_t SLICES = 8, KEEP = 8;
+    const uint32_t SLICES = 8, KEEP = 3;
     const unsigned T = host_threads();
     std::vector<uint32_t> cand((size_t)n_cold * KEEP, NONE);
     auto mix = [](uint32_t f, uint32_t l) { uint64_t z = ((uint64_t)f << 20 ^ l) * 0x9E3779B97F4A7C15ull; return z ^ (z >> 29); };
