@@ -96,3 +96,25 @@ def test_the_clustered_plan_does_not_depend_on_the_number_of_host_threads(graph,
     many = _plan(graph, monkeypatch, True)
     assert np.array_equal(one.pos_of_slot, many.pos_of_slot)
     assert one.sweep == many.sweep
+
+
+def test_sweep_stats_refuses_bad_arguments():
+    import ctypes as C
+    from protocol_amd import _ffi
+    from protocol_amd.graph import lib, _ptr
+
+    frm, to, val = pa.synth_graph(2, 1 << 10, 1 << 13, seed=1, value_max=255)
+    opts = _ffi.EtBuildOpts(1, 0, 0, 0, 0, -1, 1)
+    h = C.c_void_p()
+    assert lib().et_plan_build(1 << 10, None, len(frm), _ptr(frm), _ptr(to), _ptr(val), None, C.byref(opts), C.byref(h)) == 0
+    try:
+        ss = _ffi.EtSweepStats()
+        assert lib().et_plan_sweep_stats(h, 0, C.byref(ss)) == _ffi.ET_E_INVALID_ARG
+        assert lib().et_plan_sweep_stats(h, 3, C.byref(ss)) == _ffi.ET_E_INVALID_ARG
+        assert lib().et_plan_sweep_stats(None, _ffi.ET_VARIANT_F64, C.byref(ss)) == _ffi.ET_E_INVALID_ARG
+        assert lib().et_plan_sweep_stats(h, _ffi.ET_VARIANT_F64, None) == _ffi.ET_E_INVALID_ARG
+        # a graph this small runs the f64 sweep but not the exact one (row per lane below 16K rows)
+        assert lib().et_plan_sweep_stats(h, _ffi.ET_VARIANT_F64, C.byref(ss)) == 0 and ss.blocks > 0 and ss.edges > 0
+        assert lib().et_plan_sweep_stats(h, _ffi.ET_VARIANT_FR, C.byref(ss)) == 0 and ss.blocks == 0
+    finally:
+        lib().et_plan_free(h)
