@@ -301,7 +301,9 @@ static void cluster_cold_sources(PlanCommon& pc, const PeerStats& st, const Buil
     const Geometry& geo = g.geo;
     const BuildInput& in = pc.in;
     std::vector<uint32_t>& order = pc.order;
-    const uint32_t n = in.n, n_active = geo.n_active, B = geo.f64_blocks;
+    // one cluster per workgroup of the sweep with the most workgroups (the exact sweep's rows take more LDS, so it may run a
+    // multiple of the f64 sweep's count; the f64 sweep then gives each workgroup several whole clusters)
+    const uint32_t n = in.n, n_active = geo.n_active, B = std::max(geo.f64_blocks, geo.fr_blocks);
     const uint32_t max_deg = getenv("ET_AFFINITY_MAX_DEG") ? (uint32_t)atoi(getenv("ET_AFFINITY_MAX_DEG")) : 16;
     const uint32_t rounds = getenv("ET_AFFINITY_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("ET_AFFINITY_ROUNDS"))) : 3;
     const uint32_t n_agroups = geo.n_active_pad / BLOCK_GROUP;
@@ -534,7 +536,7 @@ int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& pc, std:
     if ((rc = layout_common(in.n, in.member, g.values_are_u32, pc.dangling, st, opt, g, pc.order, err))) return rc;
     {
         const char* e = getenv("ET_AFFINITY");
-        if (opt.n_seg == 1 && g.geo.n_chunks == 1 && g.geo.fr_blocks != 0 && g.geo.fr_blocks == g.geo.f64_blocks && !(e && atoi(e) == 0))
+        if (opt.n_seg == 1 && g.geo.n_chunks == 1 && g.geo.fr_blocks != 0 && g.geo.fr_blocks % g.geo.f64_blocks == 0 && !(e && atoi(e) == 0))
             cluster_cold_sources(pc, st, opt);
     }
     // ---- 6. per-position source factors ------------------------------------------------------
@@ -737,8 +739,11 @@ int lay_out_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned
             std::vector<uint32_t> by_weight;
             by_weight.reserve(g1 - g0);
             // groups placed with the sources their workgroup gathers (cluster_cold_sources) go where they were meant to
+            // (the planner clusters for the sweep with the most workgroups; a sweep with a divisor of that count gives each of its
+            // workgroups several whole clusters)
             for (uint32_t gi = g0; gi < g1; ++gi) {
-                const uint32_t h = hinted && gi < g.grp_hint.size() ? g.grp_hint[gi] : 0xFFFFFFFFu;
+                uint32_t h = hinted && gi < g.grp_hint.size() ? g.grp_hint[gi] : 0xFFFFFFFFu;
+                if (h != 0xFFFFFFFFu) h %= n_blocks;
                 if (h < n_blocks && used[h] < gpb) place(gi, h);
                 else by_weight.push_back(gi);
             }
@@ -753,7 +758,7 @@ int lay_out_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned
             }
         };
         pass(first_dangling_group, n_groups, dblocks, false);
-        pass(0, first_dangling_group, B, g.hint_blocks == B && G == 1);
+        pass(0, first_dangling_group, B, g.hint_blocks != 0 && g.hint_blocks % B == 0 && G == 1);
         for (uint32_t bb = 0; bb < B; ++bb) ptr[bb + 1] = ptr[bb] + edges[bb];
         return d;
     };
@@ -990,7 +995,7 @@ SweepStats sweep_stats(const HostGraph& g, bool exact) {
     const uint32_t B = exact ? g.geo.fr_blocks : g.geo.f64_blocks, shift = exact ? 2 : 4;
     if (B == 0 || ptr.size() != (size_t)B + 1 || col.size() < ptr[B]) return ss;
     ss.blocks = B;
-    ss.clustered = g.hint_blocks == B && !g.grp_hint.empty();
+    ss.clustered = g.hint_blocks != 0 && g.hint_blocks % B == 0 && !g.grp_hint.empty();
     ss.edges = ptr[B];
     for (uint32_t b = 0; b < B; ++b) {
         uint64_t c = 0;

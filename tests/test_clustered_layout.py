@@ -54,13 +54,14 @@ def test_small_graphs_and_several_shares_keep_the_degree_order(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_clustered_and_plain_positions_give_the_same_scores_on_the_gpu(monkeypatch):
+@pytest.mark.parametrize("n,m", [(1 << 19, 1 << 23), (5 << 18, 3 << 22)])
+def test_clustered_and_plain_positions_give_the_same_scores_on_the_gpu(monkeypatch, n, m):
     """Positions are internal: with the peers clustered by consumer or in plain degree order the exact variant returns
     the same bits (and the CPU checker's), the f64 variant the same scores to 1e-9 relative L1.  Empty slots, peers
-    without opinions and repeated attestation pairs included."""
+    without opinions and repeated attestation pairs included.  The second size runs the exact sweep on twice the f64
+    sweep's workgroups: every cluster of the planner is shared by two of them."""
     import c_oracle
 
-    n, m = 1 << 19, 1 << 23
     frm, to, val = pa.synth_graph(3, n, m, seed=5, value_max=255)
     rng = np.random.default_rng(5)
     member = (rng.random(n) > 0.02).astype(np.uint8)
