@@ -198,7 +198,7 @@ int et_plan_arrays_get(const et_plan *p, et_plan_arrays *out);
  * will cost before uploading.  line_fills = distinct (workgroup, 128-byte line of the trust vector) pairs of one launch:
  * the number of lines the compute units pull into their L1s, which is what bounds a sweep.  clustered = 1 when the
  * positions of peers with few opinions were placed beside the peers the same workgroup gathers (one share, byte
- * opinions, both variants on the sweep with the same workgroup count; ET_AFFINITY=0 switches it off). */
+ * opinions, both variants on the sweep, one's workgroup count a multiple of the other's; ET_AFFINITY=0 switches it off). */
 typedef struct {
     uint32_t blocks;          /* workgroups; 0 = this variant does not run the blocked sweep on this plan */
     uint32_t clustered;
