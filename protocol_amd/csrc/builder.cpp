@@ -304,7 +304,11 @@ static void cluster_cold_sources(PlanCommon& pc, const PeerStats& st, const Buil
     // one cluster per workgroup of the sweep with the most workgroups (the exact sweep's rows take more LDS, so it may run a
     // multiple of the f64 sweep's count; the f64 sweep then gives each workgroup several whole clusters)
     const uint32_t n = in.n, n_active = geo.n_active, B = std::max(geo.f64_blocks, geo.fr_blocks);
-    const uint32_t max_deg = getenv("ET_AFFINITY_MAX_DEG") ? (uint32_t)atoi(getenv("ET_AFFINITY_MAX_DEG")) : 16;
+    // Who is clustered: a line of the f64 vector holds 16 sources; when they have more out-edges together than the sweep has
+    // workgroups, nearly every workgroup gathers from the line anyway and the sources are better off among their like, in order
+    // of out-degree.  Hence: out-degree up to workgroups / 16 (16 for one workgroup per CU; measured optimum 12-16 for the f64
+    // sweep, 16-32 for the exact one, whose lines hold four sources).
+    const uint32_t max_deg = getenv("ET_AFFINITY_MAX_DEG") ? (uint32_t)atoi(getenv("ET_AFFINITY_MAX_DEG")) : std::max<uint32_t>(4, geo.f64_blocks / 16);
     const uint32_t rounds = getenv("ET_AFFINITY_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("ET_AFFINITY_ROUNDS"))) : 3;
     const uint32_t n_agroups = geo.n_active_pad / BLOCK_GROUP;
     // below about a thousand rows per workgroup the lines are dense anyway (every workgroup gathers from most of them): measured
