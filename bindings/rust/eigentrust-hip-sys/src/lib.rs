@@ -83,7 +83,9 @@ pub struct et_build_opts {
     pub variants: u32,
     pub device: i32,
     pub n_chunks: u32,
+    pub flags: u32,
 }
+pub const ET_BUILD_FULL_VECTOR: u32 = 1;
 
 #[repr(C)]
 #[derive(Clone, Copy, Default)]
@@ -106,6 +108,26 @@ pub struct et_graph_info {
     pub exact_sweep_blocks: u32,
     pub n_chunks: u32,
     pub chunk_rows: u32,
+    pub gather: u32,
+    pub full_len: u64,
+}
+
+/// What a share sends to and receives from the others between two steps (entries, not bytes).
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct et_exchange_info {
+    pub gather: u32,
+    pub n_seg: u32,
+    pub seg: u32,
+    pub own_off: u32,
+    pub own_len: u32,
+    pub vec_len: u64,
+    pub full_len: u64,
+    pub recv_off: [u32; 8],
+    pub recv_count: [u32; 8],
+    pub send_off: [u32; 8],
+    pub send_count: [u32; 8],
+    pub send_total: u64,
 }
 
 #[repr(C)]
@@ -242,6 +264,11 @@ extern "C" {
                                         phase: u32, stream: *mut c_void) -> c_int;
     pub fn et_graph_step_f64_phase_async(g: *mut et_graph, x: *const c_void, y: *mut c_void, iteration: u32, alpha: f64,
                                          pretrust_pos: *const c_void, flags: u32, phase: u32, stream: *mut c_void) -> c_int;
+    pub fn et_graph_exchange_get(g: *const et_graph, out: *mut et_exchange_info) -> c_int;
+    pub fn et_plan_exchange_get(p: *const et_plan, out: *mut et_exchange_info, need: *mut *const u32,
+                                send: *mut *const u32) -> c_int;
+    pub fn et_graph_pack_fr_async(g: *mut et_graph, y: *const c_void, send: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn et_graph_pack_f64_async(g: *mut et_graph, y: *const c_void, send: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn et_graph_unpermute_fr_async(g: *mut et_graph, x: *const c_void, out_slots: *mut c_void,
                                        stream: *mut c_void) -> c_int;
     pub fn et_graph_unpermute_f64_async(g: *mut et_graph, x: *const c_void, out_slots: *mut c_void,
@@ -289,9 +316,12 @@ extern "C" {
     pub fn et_dplan_create(n: u32, member: *const u8, n_edges: u64, from: *const u32, to: *const u32,
                            value_u32: *const u32, out: *mut *mut et_dplan) -> c_int;
     pub fn et_dplan_local_stats(p: *const et_dplan, row_sum: *mut u64, in_degree: *mut u32, out_degree: *mut u32,
-                                value_max: *mut u32) -> c_int;
+                                attested: *mut u32, value_max: *mut u32) -> c_int;
     pub fn et_dplan_set_global_stats(p: *mut et_dplan, row_sum: *const u64, in_degree: *const u32,
-                                     out_degree: *const u32, value_max: u32, opts: *const et_build_opts) -> c_int;
+                                     out_degree: *const u32, attested: *const u32, value_max: u32,
+                                     opts: *const et_build_opts) -> c_int;
+    pub fn et_dplan_needs(p: *mut et_dplan, share: u32, count: *mut u64, rows: *mut *const u32) -> c_int;
+    pub fn et_dplan_add_wanted(p: *mut et_dplan, share: u32, count: u64, rows: *const u32) -> c_int;
     pub fn et_dplan_outgoing(p: *const et_dplan, share: u32, count: *mut u64, src: *mut *const u32,
                              row: *mut *const u32, value: *mut *const u32) -> c_int;
     pub fn et_dplan_add_incoming(p: *mut et_dplan, count: u64, src: *const u32, row: *const u32,

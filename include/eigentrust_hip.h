@@ -138,7 +138,11 @@ typedef struct {
                                runs as K launches (et_graph_step_*_phase_async), so that the exchange of
                                piece q + 1 can run beside the launch over piece q.  Honoured where both
                                variants run the blocked sweep (see et_graph_info.n_chunks)               */
+    uint32_t flags;         /* ET_BUILD_* bit mask                                                    */
 } et_build_opts;
+/* Several shares: keep every share's whole segment in the trust vectors (position order, all-gather exchange) even
+ * where the gather vector (see et_exchange_info) would be used. */
+#define ET_BUILD_FULL_VECTOR 1u
 
 typedef struct {
     uint32_t n;             /* slots                                                             */
@@ -150,7 +154,8 @@ typedef struct {
     uint64_t padded_local;  /* edge-stream entries incl. padding in this share                   */
     uint32_t n_slices, n_work;
     uint32_t rows_cap, nd_cap; /* position-space geometry: segment = rows_cap + nd_cap entries   */
-    uint64_t vec_len;       /* entries of one trust vector in position order (all segments)      */
+    uint64_t vec_len;       /* entries of the trust vectors the steps of this share read and write: all
+                               segments in position order, or this share's gather vector (gather != 0)   */
     uint64_t device_bytes;  /* device memory held by this graph                                  */
     uint32_t f64_sweep_blocks;   /* workgroups of the f64 blocked sweep (0: variant not prepared)     */
     uint32_t exact_sweep_blocks; /* workgroups of the exact blocked sweep; 0: the exact variant runs
@@ -158,6 +163,9 @@ typedef struct {
     uint32_t n_chunks;      /* pieces a segment is exchanged in (1 = whole)                            */
     uint32_t chunk_rows;    /* piece q of a segment = its entries [q*chunk_rows, (q+1)*chunk_rows); the
                                last piece runs to the end of the segment (rows_cap + nd_cap)            */
+    uint32_t gather;        /* 1: the share's vectors are gather vectors (see et_exchange_info)          */
+    uint64_t full_len;      /* n_seg * (rows_cap + nd_cap): entries of a vector in position order, which is
+                               what et_graph_unpermute_* reads                                            */
 } et_graph_info;
 
 /* Filter + normalise + lay out an attestation list (see et_set_update_op for the meaning of a
@@ -252,10 +260,43 @@ int et_graph_step_fr_phase_async(et_graph *g, const void *x, void *y, uint32_t i
 int et_graph_step_f64_phase_async(et_graph *g, const void *x, void *y, uint32_t iteration, double alpha,
                                   const void *pretrust_pos, uint32_t flags, uint32_t phase,
                                   void *stream);
-/* Position order -> slot order (device to device): out has n entries. */
+/* ---- the exchange between the shares of one graph ------------------------------------------------
+ * The reference iterates one matrix in one address space (native.rs:319-329) and has no counterpart.  Here a
+ * step writes this share's own block of y (its rows' entries, then its partial sums of the dangling peers' score
+ * mass: own_len entries at own_off) and the shares exchange before the next step.
+ *   gather == 0 (one share; field-valued opinions; a chunked exchange; ET_BUILD_FULL_VECTOR): vectors hold every
+ *     share's block in position order, own_off = seg * own_len, and the exchange is an in-place all-gather of blocks.
+ *   gather == 1 (several shares, integer opinions): a share's vectors hold its own block first (own_off = 0) and then,
+ *     for every other share p in ascending order, only the entries of p's rows that this share's rows cite, followed by
+ *     p's partial sums: recv_count[p] entries at recv_off[p].  After a step, et_graph_pack_*_async copies what every
+ *     other share c cites out of the own block of y into a send buffer of send_total entries (send_count[c] entries at
+ *     send_off[c]); an all-to-all (send block c to share c, receive block p at recv_off[p] of y) completes y.  The
+ *     16M-peer benchmark graph on 8 shares: 9.1M of 16.8M entries per share, i.e. 0.54 of the all-gather's bytes.
+ *     The LAST step's y holds plain scores of the own block only; the result in slot order needs the shares' own blocks
+ *     all-gathered into a vector in position order (full_len entries, block p at p * own_len) for et_graph_unpermute_*. */
+typedef struct {
+    uint32_t gather;
+    uint32_t n_seg, seg;
+    uint32_t own_off, own_len;
+    uint64_t vec_len, full_len;
+    uint32_t recv_off[8], recv_count[8];   /* entries; zero for the share itself                         */
+    uint32_t send_off[8], send_count[8];   /* gather == 0: every share is sent the whole own block        */
+    uint64_t send_total;                   /* entries of the pack buffer                                   */
+} et_exchange_info;
+int et_graph_exchange_get(const et_graph *g, et_exchange_info *out);
+/* Fills `send` (send_total entries of 32 / 8 bytes) from the own block of y.  gather == 0: a copy of the own block. */
+int et_graph_pack_fr_async(et_graph *g, const void *y, void *send, void *stream);
+int et_graph_pack_f64_async(et_graph *g, const void *y, void *send, void *stream);
+/* The exchange tables of a host-side plan and, with a gather vector, the lists behind them: need[p] = the local rows of
+ * share p this share cites (recv_count[p] - nd_cap entries, ascending), send[c] = the local rows of this share that
+ * share c cites (send_count[c] - nd_cap entries).  need / send: arrays of 8 pointers to fill, or NULL. */
+int et_plan_exchange_get(const et_plan *p, et_exchange_info *out, const uint32_t **need, const uint32_t **send);
+
+/* Position order -> slot order (device to device): x has full_len entries in position order, out has n entries. */
 int et_graph_unpermute_fr_async(et_graph *g, const void *x, void *out_slots, void *stream);
 int et_graph_unpermute_f64_async(et_graph *g, const void *x, void *out_slots, void *stream);
-/* Slot order -> position order for a host vector of doubles (pretrust); fills vec_len entries. */
+/* Slot order -> the order of this share's vectors for a host vector of doubles (pretrust); fills vec_len entries
+ * (a step reads the entries of the share's own block only; with a gather vector only those are filled). */
 int et_graph_permute_f64_host(const et_graph *g, const double *slots, double *pos);
 
 typedef struct {
@@ -324,35 +365,47 @@ int et_sharded_converge_f64(et_sharded *s, uint32_t num_iterations, double initi
  * the same ones (native.rs:234-283, :305-314), per attester, which is why EVERY attestation of an attester
  * must be given to the same process, in its original order.  Integer opinions only.
  *   1. et_dplan_create        : this process's attestations; filter, row sums, degrees.
- *   2. et_dplan_local_stats   : per-peer figures (n entries each).  The caller sums row_sum, in_degree and
- *                               out_degree over the processes and takes the maximum of value_max (one
- *                               all-reduce each), then
+ *   2. et_dplan_local_stats   : per-peer figures (n entries each).  The caller sums row_sum, in_degree, out_degree
+ *                               and attested (the number of surviving attestations an attester wrote, whatever
+ *                               their values) over the processes and takes the maximum of value_max (one
+ *                               all-reduce each; the maximum as an unsigned or 64-bit number), then
  *      et_dplan_set_global_stats: the summed figures and the build options (n_seg = number of shares, seg =
- *                               this process's share; variants, device, n_chunks as for et_graph_build).
+ *                               this process's share; variants, device, n_chunks, flags as for et_graph_build).
  *                               Every process derives the same order, geometry and positions.
- *                               ET_E_INVALID_ARG when an attester's attestations reached two processes.
+ *                               ET_E_INVALID_ARG when an attester's attestations reached two processes, or when
+ *                               value_max is below this process's own maximum.
  *   3. et_dplan_outgoing      : the surviving local edges whose destination row share `share` owns, as three
  *                               parallel arrays (source position code, destination local row, opinion); the
  *                               caller delivers them (one all-to-all), own share included, and hands what it
  *                               received to et_dplan_add_incoming, in any order, in any number of calls.
- *   4. et_dplan_finish        : lays out the share from the records received and uploads it; the graph steps
+ *   4. et_dplan_needs         : (ends step 3) the local rows of share `share` that this share's rows cite,
+ *                               ascending; the caller delivers each list to its share (one all-to-all) and hands
+ *                               what share c sent it to et_dplan_add_wanted(c): the rows this share packs for c
+ *                               after every step (see et_exchange_info).  Lists are empty for the share itself and
+ *                               in layouts without a gather vector (et_dplan_info_get: gather == 0), where step 4
+ *                               may be skipped.
+ *   5. et_dplan_finish        : lays out the share from the records received and uploads it; the graph steps
  *                               and exchanges like one built by et_graph_build with the same n_seg / seg, and
  *                               its results are the same bits.
- * The pointers et_dplan_outgoing returns stay valid until et_dplan_finish or et_dplan_free.
+ * The pointers et_dplan_outgoing returns stay valid until et_dplan_needs, et_dplan_finish or et_dplan_free; those of
+ * et_dplan_needs until et_dplan_finish or et_dplan_free.
  * ---------------------------------------------------------------------------------------- */
 typedef struct et_dplan et_dplan;
 int et_dplan_create(uint32_t n, const uint8_t *member, uint64_t n_edges, const uint32_t *from,
                     const uint32_t *to, const uint32_t *value_u32, et_dplan **out);
 int et_dplan_local_stats(const et_dplan *p, uint64_t *row_sum, uint32_t *in_degree,
-                         uint32_t *out_degree, uint32_t *value_max);
+                         uint32_t *out_degree, uint32_t *attested, uint32_t *value_max);
 int et_dplan_set_global_stats(et_dplan *p, const uint64_t *row_sum, const uint32_t *in_degree,
-                              const uint32_t *out_degree, uint32_t value_max,
+                              const uint32_t *out_degree, const uint32_t *attested, uint32_t value_max,
                               const et_build_opts *opts);
 int et_dplan_outgoing(const et_dplan *p, uint32_t share, uint64_t *count, const uint32_t **src,
                       const uint32_t **row, const uint32_t **value);
 int et_dplan_add_incoming(et_dplan *p, uint64_t count, const uint32_t *src, const uint32_t *row,
                           const uint32_t *value);
-/* Geometry of the share (n_valid, n_dangling, nnz, rows_cap, nd_cap, vec_len, n_chunks ...): valid after step 2. */
+int et_dplan_needs(et_dplan *p, uint32_t share, uint64_t *count, const uint32_t **rows);
+int et_dplan_add_wanted(et_dplan *p, uint32_t share, uint64_t count, const uint32_t *rows);
+/* Geometry of the share (n_valid, n_dangling, nnz, rows_cap, nd_cap, full_len, gather, n_chunks ...): valid after
+ * step 2; vec_len of a gather vector once et_dplan_needs has run. */
 int et_dplan_info_get(const et_dplan *p, et_graph_info *info);
 int et_dplan_finish(et_dplan *p, et_graph **out);
 /* Step 4 without a GPU: the share's host-side plan (et_plan_info_get, et_plan_arrays_get, et_graph_from_plan). */

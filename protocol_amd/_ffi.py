@@ -45,7 +45,10 @@ class EtFr(C.Structure):
 class EtBuildOpts(C.Structure):
     _fields_ = [("n_seg", C.c_uint32), ("seg", C.c_uint32), ("long_row", C.c_uint32),
                 ("target_work", C.c_uint32), ("variants", C.c_uint32), ("device", C.c_int32),
-                ("n_chunks", C.c_uint32)]
+                ("n_chunks", C.c_uint32), ("flags", C.c_uint32)]
+
+
+ET_BUILD_FULL_VECTOR = 1
 
 
 class EtGraphInfo(C.Structure):
@@ -56,7 +59,17 @@ class EtGraphInfo(C.Structure):
                 ("rows_cap", C.c_uint32), ("nd_cap", C.c_uint32),
                 ("vec_len", C.c_uint64), ("device_bytes", C.c_uint64),
                 ("f64_sweep_blocks", C.c_uint32), ("exact_sweep_blocks", C.c_uint32),
-                ("n_chunks", C.c_uint32), ("chunk_rows", C.c_uint32)]
+                ("n_chunks", C.c_uint32), ("chunk_rows", C.c_uint32),
+                ("gather", C.c_uint32), ("full_len", C.c_uint64)]
+
+
+class EtExchangeInfo(C.Structure):
+    _fields_ = [("gather", C.c_uint32), ("n_seg", C.c_uint32), ("seg", C.c_uint32),
+                ("own_off", C.c_uint32), ("own_len", C.c_uint32),
+                ("vec_len", C.c_uint64), ("full_len", C.c_uint64),
+                ("recv_off", C.c_uint32 * 8), ("recv_count", C.c_uint32 * 8),
+                ("send_off", C.c_uint32 * 8), ("send_count", C.c_uint32 * 8),
+                ("send_total", C.c_uint64)]
 
 
 class EtSliceDesc(C.Structure):
@@ -136,6 +149,10 @@ PROTOTYPES = {
     "et_graph_step_f64_async": (i32, [vp, vp, vp, u32, dbl, vp, u32, vp]),
     "et_graph_step_fr_phase_async": (i32, [vp, vp, vp, u32, u32, u32, vp]),
     "et_graph_step_f64_phase_async": (i32, [vp, vp, vp, u32, dbl, vp, u32, u32, vp]),
+    "et_graph_exchange_get": (i32, [vp, P(EtExchangeInfo)]),
+    "et_plan_exchange_get": (i32, [vp, P(EtExchangeInfo), P(vp), P(vp)]),
+    "et_graph_pack_fr_async": (i32, [vp, vp, vp, vp]),
+    "et_graph_pack_f64_async": (i32, [vp, vp, vp, vp]),
     "et_graph_unpermute_fr_async": (i32, [vp, vp, vp, vp]),
     "et_graph_unpermute_f64_async": (i32, [vp, vp, vp, vp]),
     "et_graph_permute_f64_host": (i32, [vp, vp, vp]),
@@ -164,10 +181,12 @@ PROTOTYPES = {
     "et_synth_graph": (i32, [u32, u32, u64, u64, u32, P(u64), vp, vp, vp]),
     "et_synth_graph_range": (i32, [u32, u32, u64, u64, u32, u32, u32, P(u64), vp, vp, vp]),
     "et_dplan_create": (i32, [u32, vp, u64, vp, vp, vp, P(vp)]),
-    "et_dplan_local_stats": (i32, [vp, vp, vp, vp, P(u32)]),
-    "et_dplan_set_global_stats": (i32, [vp, vp, vp, vp, u32, P(EtBuildOpts)]),
+    "et_dplan_local_stats": (i32, [vp, vp, vp, vp, vp, P(u32)]),
+    "et_dplan_set_global_stats": (i32, [vp, vp, vp, vp, vp, u32, P(EtBuildOpts)]),
     "et_dplan_outgoing": (i32, [vp, u32, P(u64), P(vp), P(vp), P(vp)]),
     "et_dplan_add_incoming": (i32, [vp, u64, vp, vp, vp]),
+    "et_dplan_needs": (i32, [vp, u32, P(u64), P(vp)]),
+    "et_dplan_add_wanted": (i32, [vp, u32, u64, vp]),
     "et_dplan_info_get": (i32, [vp, P(EtGraphInfo)]),
     "et_dplan_finish": (i32, [vp, P(vp)]),
     "et_dplan_finish_host": (i32, [vp, P(vp)]),

@@ -126,6 +126,10 @@ int layout_common(uint32_t n, const uint8_t* member, bool values_are_u32, const 
         const uint32_t cr = round_up((geo.rows_cap + K - 1) / K, 64);
         if ((uint64_t)(K - 1) * cr < geo.rows_cap) { geo.n_chunks = K; geo.chunk_rows = cr; }
     }
+    // several shares, integer opinions, one exchange per iteration: a share's vectors hold the entries its rows cite, not
+    // every share's whole segment
+    geo.compact = (G > 1 && values_are_u32 && geo.n_chunks == 1 && !opt.full_vector && !getenv("ET_FULL_VECTOR")) ? 1u : 0u;
+    geo.set_share(opt.seg);
     g.geo = geo;
     if (G > 8 || geo.seg_stride() >= COL_LOCAL_MASK) {
         err = "more than 8 segments or more than 2^29 rows per segment";
@@ -558,17 +562,20 @@ namespace {
 // ... from the attestation list itself (one process holds all of it): attesters are walked in visit order.
 struct AttesterWalk {
     const PlanCommon& pc;
-    const HostGraph& g;
+    HostGraph& g;
     unsigned T;
     std::vector<uint32_t> lr_of_edge;   // local row of edge k's destination, ~0 = dropped or another segment's
-    std::vector<uint32_t> by_pos;       // active attesters in visit order
+    std::vector<uint32_t> by_pos;       // attesters with edges into this share's rows, in visit order
     std::vector<uint32_t> chunk_cut;    // T + 1 cuts of by_pos with about equal edge counts
+    std::vector<uint32_t> code_of_ext;  // the source index the share's edge records carry for each attester
 
-    AttesterWalk(const PlanCommon& pc_, const HostGraph& g_, unsigned T_) : pc(pc_), g(g_), T(T_) {
-        const Geometry& geo = g.geo;
+    // Fills g.need / g.send and the geometry of the gather vector (geo.compact), then the visit order.
+    AttesterWalk(const PlanCommon& pc_, HostGraph& g_, unsigned T_) : pc(pc_), g(g_), T(T_) {
+        Geometry& geo = g.geo;
         const BuildInput& in = pc.in;
-        const uint32_t my_base = geo.seg * geo.seg_stride();
-        const uint64_t n_kept = pc.out_ptr[in.n];
+        const uint32_t stride = geo.seg_stride(), n = in.n;
+        const uint32_t my_base = geo.seg * stride;
+        const uint64_t n_kept = pc.out_ptr[n];
         lr_of_edge.resize(n_kept);
         run_threads(T, [&](unsigned t) {
             for (uint64_t k = n_kept * t / T; k < n_kept * (t + 1) / T; ++k) {
@@ -580,21 +587,68 @@ struct AttesterWalk {
                 lr_of_edge[k] = lr;
             }
         });
-        by_pos.assign(pc.order.begin(), pc.order.begin() + geo.n_active);
+        const uint32_t n_active = geo.n_active;
+        code_of_ext.assign(n, 0xFFFFFFFFu);
+        if (geo.compact) {
+            // who is cited here, and which shares cite this share's own rows (bit c of `wanted`)
+            std::vector<uint8_t> cited(n, 0), wanted(n, 0);
+            run_threads(T, [&](unsigned t) {
+                for (uint32_t f = (uint32_t)((uint64_t)n * t / T); f < (uint32_t)((uint64_t)n * (t + 1) / T); ++f) {
+                    if (pc.dangling[f] || g.pos_of_ext[f] == 0xFFFFFFFFu) continue;
+                    const bool mine = g.pos_of_ext[f] / stride == geo.seg;
+                    uint8_t c = 0, w = 0;
+                    for (uint64_t k = pc.out_ptr[f]; k < pc.out_ptr[f + 1]; ++k) {
+                        if (pc.drop[k]) continue;
+                        if (lr_of_edge[k] != 0xFFFFFFFFu) c = 1;
+                        else if (mine) w |= (uint8_t)(1u << (g.pos_of_ext[in.to[pc.kept[k]]] / stride));
+                    }
+                    cited[f] = c;
+                    wanted[f] = w;
+                }
+            });
+            for (uint32_t p = 0; p < 8; ++p) { g.need[p].clear(); g.send[p].clear(); }
+            // ranks ascend with the local row inside every share, so the lists come out ascending
+            for (uint32_t r = 0; r < n_active; ++r) {
+                const uint32_t f = pc.order[r], pos = g.pos_of_ext[f], p = pos / stride, local = pos % stride;
+                if (p == geo.seg) {
+                    for (uint32_t c = 0; c < geo.n_seg; ++c) if (wanted[f] >> c & 1) g.send[c].push_back(local);
+                } else if (cited[f]) {
+                    g.need[p].push_back(local);
+                }
+            }
+            g.send_known = true;
+            uint32_t counts[8];
+            for (uint32_t p = 0; p < 8; ++p) counts[p] = (uint32_t)g.need[p].size();
+            geo.set_gather_blocks(counts, g.blk_off);
+            std::vector<uint32_t> at(8, 0);
+            for (uint32_t r = 0; r < n_active; ++r) {
+                const uint32_t f = pc.order[r], pos = g.pos_of_ext[f], p = pos / stride;
+                if (p == geo.seg) code_of_ext[f] = pos % stride;
+                else if (cited[f]) code_of_ext[f] = g.blk_off[p] + at[p]++;
+            }
+            for (uint32_t r = 0; r < n_active; ++r) if (cited[pc.order[r]]) by_pos.push_back(pc.order[r]);
+        } else {
+            for (uint32_t r = 0; r < n_active; ++r) {
+                const uint32_t f = pc.order[r], pos = g.pos_of_ext[f];
+                code_of_ext[f] = ((pos / stride) << COL_SEG_SHIFT) | (pos % stride);
+            }
+            by_pos.assign(pc.order.begin(), pc.order.begin() + n_active);
+        }
         auto visit_key = [&](uint32_t ext) -> uint64_t {
+            if (geo.compact) return code_of_ext[ext];
             const uint32_t p = g.pos_of_ext[ext];
-            return ((uint64_t)(geo.n_chunks > 1 ? geo.chunk_of_local(p % geo.seg_stride()) : 0u) << 32) | p;
+            return ((uint64_t)(geo.n_chunks > 1 ? geo.chunk_of_local(p % stride) : 0u) << 32) | p;
         };
         std::sort(by_pos.begin(), by_pos.end(), [&](uint32_t a, uint32_t b) { return visit_key(a) < visit_key(b); });
-        const uint32_t n_active = geo.n_active;
-        std::vector<uint64_t> pos_edges((size_t)n_active + 1, 0);
-        for (uint32_t i = 0; i < n_active; ++i) pos_edges[i + 1] = pos_edges[i] + (pc.out_ptr[by_pos[i] + 1] - pc.out_ptr[by_pos[i]]);
-        chunk_cut.assign(T + 1, n_active);
+        const uint32_t n_walk = (uint32_t)by_pos.size();
+        std::vector<uint64_t> pos_edges((size_t)n_walk + 1, 0);
+        for (uint32_t i = 0; i < n_walk; ++i) pos_edges[i + 1] = pos_edges[i] + (pc.out_ptr[by_pos[i] + 1] - pc.out_ptr[by_pos[i]]);
+        chunk_cut.assign(T + 1, n_walk);
         chunk_cut[0] = 0;
         for (unsigned t = 1; t < T; ++t)
-            chunk_cut[t] = (uint32_t)(std::lower_bound(pos_edges.begin(), pos_edges.end(), pos_edges[n_active] * t / T) - pos_edges.begin());
-        for (unsigned t = 1; t <= T; ++t) chunk_cut[t] = std::min<uint32_t>(n_active, std::max(chunk_cut[t], chunk_cut[t - 1]));
-        chunk_cut[T] = n_active;
+            chunk_cut[t] = (uint32_t)(std::lower_bound(pos_edges.begin(), pos_edges.end(), pos_edges[n_walk] * t / T) - pos_edges.begin());
+        for (unsigned t = 1; t <= T; ++t) chunk_cut[t] = std::min<uint32_t>(n_walk, std::max(chunk_cut[t], chunk_cut[t - 1]));
+        chunk_cut[T] = n_walk;
     }
     void count_rows(std::vector<uint64_t>& in_ptr) const {
         const uint32_t n = pc.in.n;
@@ -610,11 +664,9 @@ struct AttesterWalk {
     }
     template <typename V>
     void walk(unsigned t, V visit) const {
-        const Geometry& geo = g.geo;
         for (uint32_t i = chunk_cut[t]; i < chunk_cut[t + 1]; ++i) {
             const uint32_t f = by_pos[i];
-            uint32_t pf = g.pos_of_ext[f];
-            pf = ((pf / geo.seg_stride()) << COL_SEG_SHIFT) | (pf % geo.seg_stride());
+            const uint32_t pf = code_of_ext[f];
             for (uint64_t k = pc.out_ptr[f]; k < pc.out_ptr[f + 1]; ++k) {
                 const uint32_t lr = lr_of_edge[k];
                 if (lr != 0xFFFFFFFFu) visit(lr, pf, pc.kept[k]);
@@ -625,22 +677,28 @@ struct AttesterWalk {
     const FrRaw& value_fr(uint64_t h) const { return pc.in.val_fr[h]; }
 };
 
-// ... from edge records that other processes sent: (source code, local row, integer opinion), any order on arrival
+// ... from edge records that other processes sent: (source code = (segment << 29) | local row, local row of the
+// destination, integer opinion), any order on arrival
 struct RecordWalk {
-    const Geometry geo;
+    Geometry geo;
     unsigned T;
     uint64_t count;
-    std::vector<uint32_t> src, row, val;   // sorted by the source's visit key
+    std::vector<uint32_t> src, row, val;   // sorted by the source's visit key; src = the source index the edge records carry
 
-    RecordWalk(const Geometry& geo_, unsigned T_, const std::vector<uint32_t>& src_in, const std::vector<uint32_t>& row_in,
-               const std::vector<uint32_t>& val_in) : geo(geo_), T(T_), count(src_in.size()) {
-        // sort by visit key: T buckets of equal key ranges (sources are spread evenly over the positions), each sorted by its owner
+    // Sorts the records; with a gather vector also fills g.need and the geometry of the gather vector.
+    RecordWalk(HostGraph& g, unsigned T_, const std::vector<uint32_t>& src_in, const std::vector<uint32_t>& row_in,
+               const std::vector<uint32_t>& val_in) : geo(g.geo), T(T_), count(src_in.size()) {
+        const uint32_t stride = geo.seg_stride();
+        // visit key: position (piece by piece with a chunked exchange); gather vector: the share's own block first, then
+        // the other shares' in ascending order, local rows ascending inside a block
+        auto block_rank = [&](uint32_t p) -> uint32_t { return !geo.compact ? p : (p == geo.seg ? 0u : (p < geo.seg ? p + 1 : p)); };
         auto key_of = [&](uint32_t code) -> uint64_t {
             const uint32_t local = code & COL_LOCAL_MASK;
-            return ((uint64_t)(geo.n_chunks > 1 ? geo.chunk_of_local(local) : 0u) << 32) | geo.pos_of_col(code);
+            return ((uint64_t)(geo.n_chunks > 1 ? geo.chunk_of_local(local) : 0u) << 32) | ((uint64_t)block_rank(code >> COL_SEG_SHIFT) * stride + local);
         };
+        // sort by visit key: T buckets of equal key ranges (sources are spread evenly over the positions), each sorted by its owner
         // bucket = position of the key in [0, key_end) taken over (piece, position / vector length)
-        const uint64_t vec_len = (uint64_t)geo.n_seg * geo.seg_stride();
+        const uint64_t vec_len = (uint64_t)geo.n_seg * stride;
         auto bucket_of = [&](uint64_t key) -> unsigned {
             const long double frac = ((long double)(key >> 32) + (long double)(key & 0xFFFFFFFFull) / (long double)vec_len) / (long double)geo.n_chunks;
             return (unsigned)std::min<long double>(T - 1, frac * T);
@@ -673,13 +731,42 @@ struct RecordWalk {
             });
         });
         src.resize(count); row.resize(count); val.resize(count);
-        const uint32_t stride = geo.seg_stride();
         run_threads(T, [&](unsigned t) {
-            for (uint64_t k = count * t / T; k < count * (t + 1) / T; ++k) {
-                const uint32_t pos = (uint32_t)(buf[k].key & 0xFFFFFFFFull);
-                src[k] = ((pos / stride) << COL_SEG_SHIFT) | (pos % stride);
-                row[k] = buf[k].row;
-                val[k] = buf[k].val;
+            for (uint64_t k = count * t / T; k < count * (t + 1) / T; ++k) { row[k] = buf[k].row; val[k] = buf[k].val; }
+        });
+        if (!geo.compact) {
+            run_threads(T, [&](unsigned t) {
+                for (uint64_t k = count * t / T; k < count * (t + 1) / T; ++k) {
+                    const uint32_t pos = (uint32_t)(buf[k].key & 0xFFFFFFFFull);
+                    src[k] = ((pos / stride) << COL_SEG_SHIFT) | (pos % stride);
+                }
+            });
+            return;
+        }
+        // gather vector: the distinct sources of every other share, ascending, are what this share needs from it
+        auto share_of_rank = [&](uint32_t br) -> uint32_t { return br == 0 ? geo.seg : (br <= geo.seg ? br - 1 : br); };
+        for (uint32_t p = 0; p < 8; ++p) { g.need[p].clear(); }
+        for (uint64_t k = 0; k < count; ++k) {
+            const uint32_t v = (uint32_t)(buf[k].key & 0xFFFFFFFFull), br = v / stride;
+            if (br == 0 || (k && buf[k - 1].key == buf[k].key)) continue;
+            g.need[share_of_rank(br)].push_back(v % stride);
+        }
+        uint32_t counts[8];
+        for (uint32_t p = 0; p < 8; ++p) counts[p] = (uint32_t)g.need[p].size();
+        g.geo.set_gather_blocks(counts, g.blk_off);
+        geo = g.geo;
+        run_threads(T, [&](unsigned t) {
+            uint64_t k = count * t / T;
+            const uint64_t k1 = count * (t + 1) / T;
+            while (k < k1) {
+                const uint32_t v = (uint32_t)(buf[k].key & 0xFFFFFFFFull), br = v / stride, local = v % stride;
+                uint32_t code = local;
+                if (br != 0) {
+                    const uint32_t p = share_of_rank(br);
+                    code = g.blk_off[p] + (uint32_t)(std::lower_bound(g.need[p].begin(), g.need[p].end(), local) - g.need[p].begin());
+                }
+                const uint64_t key = buf[k].key;
+                for (; k < k1 && buf[k].key == key; ++k) src[k] = code;
             }
         });
     }
@@ -1015,25 +1102,52 @@ int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index,
     if (seg_index >= pc.g.geo.n_seg) { err = "bad segment"; return ET_E_INVALID_ARG; }
     // everything that does not depend on the segment: filter results, order, positions, factors
     g = pc.g;
-    g.geo.seg = seg_index;
+    g.geo.set_share(seg_index);
     const unsigned T = host_threads();
     AttesterWalk src(pc, g, T);
+    if (g.geo.vec_len >= COL_LOCAL_MASK) { err = "more than 2^29 entries in a share's gather vector"; return ET_E_UNSUPPORTED; }
     return lay_out_segment(g, opt, src, T, err);
 }
 
-int plan_segment_from_records(HostGraph& g, const BuildOpts& opt, uint32_t seg_index, const std::vector<uint32_t>& src_code,
-                              const std::vector<uint32_t>& row, const std::vector<uint32_t>& val, std::string& err) {
+struct SortedRecords {
+    RecordWalk walk;
+    SortedRecords(HostGraph& g, unsigned T, const std::vector<uint32_t>& s, const std::vector<uint32_t>& r, const std::vector<uint32_t>& v)
+        : walk(g, T, s, r, v) {}
+};
+void free_sorted_records(SortedRecords* r) { delete r; }
+
+int records_to_needs(HostGraph& g, uint32_t seg_index, const std::vector<uint32_t>& src_code, const std::vector<uint32_t>& row,
+                     const std::vector<uint32_t>& val, SortedRecords** out, std::string& err) {
     if (seg_index >= g.geo.n_seg) { err = "bad segment"; return ET_E_INVALID_ARG; }
     if (!g.values_are_u32) { err = "edge records carry integer opinions only"; return ET_E_UNSUPPORTED; }
     if (src_code.size() != row.size() || row.size() != val.size()) { err = "edge record arrays differ in length"; return ET_E_INVALID_ARG; }
-    g.geo.seg = seg_index;
+    g.geo.set_share(seg_index);
     for (size_t k = 0; k < row.size(); ++k) {
         const uint32_t s = src_code[k] >> COL_SEG_SHIFT, l = src_code[k] & COL_LOCAL_MASK;
         if (row[k] >= g.geo.rows_cap || s >= g.geo.n_seg || l >= g.geo.rows_cap) { err = "edge record out of range"; return ET_E_OUT_OF_RANGE; }
     }
-    const unsigned T = host_threads();
-    RecordWalk src(g.geo, T, src_code, row, val);
-    return lay_out_segment(g, opt, src, T, err);
+    *out = new SortedRecords(g, host_threads(), src_code, row, val);
+    if (g.geo.vec_len >= COL_LOCAL_MASK) { delete *out; *out = nullptr; err = "more than 2^29 entries in a share's gather vector"; return ET_E_UNSUPPORTED; }
+    return ET_OK;
+}
+
+int plan_segment_from_sorted(HostGraph& g, const BuildOpts& opt, SortedRecords* rec, std::string& err) {
+    if (!rec) { err = "no records"; return ET_E_INVALID_ARG; }
+    if (g.geo.compact && !g.send_known) { err = "the rows the other shares cite are not known yet"; return ET_E_INVALID_ARG; }
+    for (uint32_t c = 0; c < 8; ++c)
+        for (uint32_t l : g.send[c]) if (l >= g.geo.rows_cap) { err = "cited row out of range"; return ET_E_OUT_OF_RANGE; }
+    return lay_out_segment(g, opt, rec->walk, rec->walk.T, err);
+}
+
+int plan_segment_from_records(HostGraph& g, const BuildOpts& opt, uint32_t seg_index, const std::vector<uint32_t>& src_code,
+                              const std::vector<uint32_t>& row, const std::vector<uint32_t>& val, std::string& err) {
+    if (g.geo.compact) { err = "a share with a gather vector is laid out in two steps (records_to_needs, plan_segment_from_sorted)"; return ET_E_INVALID_ARG; }
+    SortedRecords* rec = nullptr;
+    int rc = records_to_needs(g, seg_index, src_code, row, val, &rec, err);
+    if (rc) return rc;
+    rc = plan_segment_from_sorted(g, opt, rec, err);
+    delete rec;
+    return rc;
 }
 
 int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::string& err) {

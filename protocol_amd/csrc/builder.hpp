@@ -41,6 +41,7 @@ struct BuildOpts {
     uint32_t hot_prefix = 16384; // the most-attesting (most gathered) peers take the first positions: one contiguous prefix of the vector
     uint32_t f64_blocks = 256;   // workgroups of the f64 variant (one per CU)
     uint32_t n_chunks = 1;       // pieces a segment is exchanged in (see Geometry::n_chunks); honoured where both variants run the blocked sweep
+    bool full_vector = false;    // several shares: keep every share's whole segment in the vectors (all-gather exchange) instead of the cited entries only
     // Relative time a workgroup on XCD x (workgroup b runs on XCD b mod 8) needs per edge of a blocked sweep, in 1/1024
     // (1024 = the same everywhere): the deal levels edges x cost instead of edges.  Measured per device by
     // xcd_cost_factors (engine.hpp); a plan made without a device keeps the default.
@@ -91,6 +92,14 @@ struct HostGraph {
     // positions every peer above the clustering threshold).  A sweep's edges from these sources come first in every
     // workgroup's list and read a dense, cache-resident part of the vector.  0 = not known (several shares).
     uint32_t dense_prefix = 0;
+    // Several shares with a gather vector (geo.compact, see layout.hpp).  need[p]: the local rows of share p that this share's
+    // rows cite, in the order their entries take in block p of the gather vector (ascending); send[c]: the local rows of THIS
+    // share that share c cites, in c's order -- what this share packs for c after every step.  Both are empty for the share
+    // itself.  send_known: the send lists are filled (a share laid out from the whole list derives them itself; one laid out
+    // from edge records is told by the other shares).
+    std::vector<uint32_t> need[8], send[8];
+    bool send_known = false;
+    uint32_t blk_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // first entry of block p (the share's own block is [0, seg_stride()))
 };
 
 // Returns 0 or a negative ET_E_* code; `err` receives a human-readable reason.
@@ -126,6 +135,15 @@ void fill_factors_u64(HostGraph& g, const uint32_t* peers, uint32_t count, const
 // `g` holds the common part on entry (layout_common + fill_factors_u64) and the share's plan on return
 int plan_segment_from_records(HostGraph& g, const BuildOpts& opt, uint32_t seg, const std::vector<uint32_t>& src_code,
                               const std::vector<uint32_t>& row, const std::vector<uint32_t>& val, std::string& err);
+// With a gather vector the other shares must learn which of their rows this share cites before they can pack them: the same
+// in two steps.  records_to_needs sorts the records and fills g.need (and the geometry of the gather vector); the caller
+// delivers need[p] to share p and stores what the others want from this share in g.send (g.send_known = true);
+// plan_segment_from_sorted then lays out the share.  (Position-order layouts: need stays empty, nothing to deliver.)
+struct SortedRecords;
+void free_sorted_records(SortedRecords* r);
+int records_to_needs(HostGraph& g, uint32_t seg, const std::vector<uint32_t>& src_code, const std::vector<uint32_t>& row,
+                     const std::vector<uint32_t>& val, SortedRecords** out, std::string& err);
+int plan_segment_from_sorted(HostGraph& g, const BuildOpts& opt, SortedRecords* rec, std::string& err);
 // steps 1-4 alone (filter, last write wins, row sums, degrees) over the attestations given
 struct RowSums {
     std::vector<uint64_t> u64;          // integer opinions

@@ -75,6 +75,7 @@ static void read_opts(const et_build_opts* opts, BuildOpts& bo, int& variants, i
     variants = (int)opts->variants;
     device = opts->device;
     if (opts->n_chunks) bo.n_chunks = opts->n_chunks;
+    bo.full_vector = (opts->flags & ET_BUILD_FULL_VECTOR) != 0;
 }
 
 // Tuning knobs for experiments (not part of the ABI): ET_TARGET_WORK, ET_LONG_ROW, ET_F64_BLOCKS, ET_HOT_PREFIX.
@@ -127,7 +128,9 @@ static void fill_info(const HostGraph& h, et_graph_info* info) {
     info->nnz = h.nnz; info->nnz_local = h.nnz_local; info->padded_local = h.n_steps * 64;
     info->n_slices = (uint32_t)h.slices.size(); info->n_work = (uint32_t)h.work.size();
     info->rows_cap = h.geo.rows_cap; info->nd_cap = h.geo.nd_cap;
-    info->vec_len = (uint64_t)h.geo.n_seg * h.geo.seg_stride();
+    info->vec_len = h.geo.vec_len;
+    info->full_len = (uint64_t)h.geo.n_seg * h.geo.seg_stride();
+    info->gather = h.geo.compact;
     info->n_chunks = h.geo.n_chunks; info->chunk_rows = h.geo.chunk_rows;
 }
 int et_plan_info_get(const et_plan* p, et_graph_info* info) {
@@ -195,7 +198,61 @@ int et_graph_info_get(const et_graph* g, et_graph_info* info) {
     info->f64_sweep_blocks = d->n_f64_parts;
     info->exact_sweep_blocks = d->fr_blocked ? d->geo.fr_blocks : 0;
     info->n_chunks = d->geo.n_chunks; info->chunk_rows = d->geo.chunk_rows;
+    info->gather = d->geo.compact; info->full_len = d->full_len;
     return ET_OK;
+}
+
+static void exchange_common(const Geometry& geo, et_exchange_info* out) {
+    std::memset(out, 0, sizeof(*out));
+    out->gather = geo.compact; out->n_seg = geo.n_seg; out->seg = geo.seg;
+    out->own_off = geo.own_off; out->own_len = geo.seg_stride();
+    out->vec_len = geo.vec_len; out->full_len = (uint64_t)geo.n_seg * geo.seg_stride();
+}
+int et_graph_exchange_get(const et_graph* g, et_exchange_info* out) {
+    if (!g || !out) return ET_E_INVALID_ARG;
+    const DeviceGraph* d = G(g);
+    exchange_common(d->geo, out);
+    for (int c = 0; c < 8; ++c) {
+        out->recv_off[c] = d->recv_off[c]; out->recv_count[c] = d->recv_cnt[c];
+        out->send_off[c] = d->send_off[c]; out->send_count[c] = d->send_cnt[c];
+    }
+    out->send_total = d->send_total;
+    return ET_OK;
+}
+int et_plan_exchange_get(const et_plan* p, et_exchange_info* out, const uint32_t** need, const uint32_t** send) {
+    if (!p || !out) return ET_E_INVALID_ARG;
+    const HostGraph& h = p->h;
+    const Geometry& geo = h.geo;
+    exchange_common(geo, out);
+    uint32_t at = 0;
+    for (uint32_t c = 0; c < 8; ++c) {
+        if (need) need[c] = nullptr;
+        if (send) send[c] = nullptr;
+        if (c >= geo.n_seg || c == geo.seg) continue;
+        if (geo.compact) {
+            out->recv_off[c] = h.blk_off[c]; out->recv_count[c] = (uint32_t)h.need[c].size() + geo.nd_cap;
+            out->send_off[c] = at; out->send_count[c] = (uint32_t)h.send[c].size() + geo.nd_cap;
+            at += out->send_count[c];
+            if (need) need[c] = h.need[c].data();
+            if (send) send[c] = h.send[c].data();
+        } else {
+            out->recv_off[c] = c * geo.seg_stride(); out->recv_count[c] = geo.seg_stride();
+            out->send_off[c] = 0; out->send_count[c] = geo.seg_stride();
+            at = geo.seg_stride();
+        }
+    }
+    out->send_total = at;
+    return ET_OK;
+}
+int et_graph_pack_fr_async(et_graph* g, const void* y, void* send, void* stream) {
+    if (!g || !y || !send) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
+    return G(g)->pack(y, send, 32, (hipStream_t)stream);
+}
+int et_graph_pack_f64_async(et_graph* g, const void* y, void* send, void* stream) {
+    if (!g || !y || !send) return ET_E_INVALID_ARG;
+    HIP_TRY_C(hipSetDevice(G(g)->device));
+    return G(g)->pack(y, send, 8, (hipStream_t)stream);
 }
 
 int et_graph_converge_fr(et_graph* g, uint32_t num_iterations, uint64_t initial_lo, uint64_t initial_hi, et_fr* out) {
@@ -275,12 +332,14 @@ int et_graph_step_f64_async(et_graph* g, const void* x, void* y, uint32_t iterat
 }
 int et_graph_step_fr_phase_async(et_graph* g, const void* x, void* y, uint32_t iteration, uint32_t flags, uint32_t phase, void* stream) {
     if (!g || !x || !y) return ET_E_INVALID_ARG;
+    if (phase >= G(g)->geo.n_chunks) { set_error("no such phase"); return ET_E_OUT_OF_RANGE; }
     HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->step_fr((const uint4*)x, (uint4*)y, iteration, flags, (hipStream_t)stream, (int)phase);
 }
 int et_graph_step_f64_phase_async(et_graph* g, const void* x, void* y, uint32_t iteration, double alpha,
                                   const void* pretrust_pos, uint32_t flags, uint32_t phase, void* stream) {
     if (!g || !x || !y) return ET_E_INVALID_ARG;
+    if (phase >= G(g)->geo.n_chunks) { set_error("no such phase"); return ET_E_OUT_OF_RANGE; }
     HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->step_f64((const double*)x, (double*)y, iteration, alpha, (const double*)pretrust_pos, flags, (hipStream_t)stream, (int)phase);
 }
@@ -298,8 +357,13 @@ int et_graph_permute_f64_host(const et_graph* g, const double* slots, double* po
     if (!g || !slots || !pos) return ET_E_INVALID_ARG;
     const DeviceGraph* d = G(g);
     std::memset(pos, 0, d->vec_len * sizeof(double));
-    for (uint32_t i = 0; i < d->n; ++i)
-        if (d->pos_of_ext[i] != 0xFFFFFFFFu) pos[d->pos_of_ext[i]] = slots[i];
+    const uint32_t stride = d->geo.seg_stride();
+    for (uint32_t i = 0; i < d->n; ++i) {
+        const uint32_t p = d->pos_of_ext[i];
+        if (p == 0xFFFFFFFFu) continue;
+        if (!d->geo.compact) pos[p] = slots[i];
+        else if (p / stride == d->geo.seg) pos[p % stride] = slots[i];     // gather vector: the own block comes first
+    }
     return ET_OK;
 }
 int et_graph_stats_fr(et_graph* g, uint32_t iteration, void* stream, et_iter_stats* out) {

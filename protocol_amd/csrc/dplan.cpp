@@ -30,9 +30,23 @@ struct et_dplan {
     // stage 2: records by destination share
     std::vector<uint64_t> out_begin;     // n_seg + 1
     std::vector<uint32_t> out_src, out_row, out_val;
-    // stage 3
+    // stage 2: records received
     std::vector<uint32_t> in_src, in_row, in_val;
+    // stage 3 (shares with a gather vector): the records sorted, g.need known, g.send being collected
+    SortedRecords* sorted = nullptr;
+    std::vector<uint8_t> told;           // which shares have said what they cite here
+    ~et_dplan() { free_sorted_records(sorted); }
 };
+
+// surviving attestations per attester, whatever their values (a peer whose opinions here sum to zero still wrote them here)
+static void count_attested(const et_dplan* p, uint32_t* out) {
+    const std::vector<uint64_t>& out_ptr = p->pc.out_ptr;
+    for (uint32_t f = 0; f < p->n; ++f) {
+        uint32_t c = 0;
+        for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) c += p->pc.drop[k] ? 0u : 1u;
+        out[f] = c;
+    }
+}
 
 extern "C" {
 
@@ -60,19 +74,21 @@ int et_dplan_create(uint32_t n, const uint8_t* member, uint64_t n_edges, const u
     return ET_OK;
 }
 
-int et_dplan_local_stats(const et_dplan* p, uint64_t* row_sum, uint32_t* in_degree, uint32_t* out_degree, uint32_t* value_max) {
-    if (!p || !row_sum || !in_degree || !out_degree || !value_max) return ET_E_INVALID_ARG;
+int et_dplan_local_stats(const et_dplan* p, uint64_t* row_sum, uint32_t* in_degree, uint32_t* out_degree, uint32_t* attested,
+                         uint32_t* value_max) {
+    if (!p || !row_sum || !in_degree || !out_degree || !attested || !value_max) return ET_E_INVALID_ARG;
     if (p->stage != 1) { set_error("local statistics are gone once the global ones were set"); return ET_E_INVALID_ARG; }
     std::memcpy(row_sum, p->sums.u64.data(), (size_t)p->n * sizeof(uint64_t));
     std::memcpy(in_degree, p->local.in_deg.data(), (size_t)p->n * sizeof(uint32_t));
     std::memcpy(out_degree, p->local.out_deg.data(), (size_t)p->n * sizeof(uint32_t));
+    count_attested(p, attested);
     *value_max = p->local.value_max;
     return ET_OK;
 }
 
 int et_dplan_set_global_stats(et_dplan* p, const uint64_t* row_sum, const uint32_t* in_degree, const uint32_t* out_degree,
-                              uint32_t value_max, const et_build_opts* opts) {
-    if (!p || !row_sum || !in_degree || !out_degree || !opts) return ET_E_INVALID_ARG;
+                              const uint32_t* attested, uint32_t value_max, const et_build_opts* opts) {
+    if (!p || !row_sum || !in_degree || !out_degree || !attested || !opts) return ET_E_INVALID_ARG;
     if (p->stage != 1) { set_error("global statistics were already set"); return ET_E_INVALID_ARG; }
     const uint32_t n = p->n;
     BuildOpts bo;
@@ -81,17 +97,28 @@ int et_dplan_set_global_stats(et_dplan* p, const uint64_t* row_sum, const uint32
     if (opts->long_row) bo.long_row = opts->long_row;
     if (opts->target_work) bo.target_work = opts->target_work;
     if (opts->n_chunks) bo.n_chunks = opts->n_chunks;
+    bo.full_vector = (opts->flags & ET_BUILD_FULL_VECTOR) != 0;
     if (bo.seg >= bo.n_seg) { set_error("bad segment"); return ET_E_INVALID_ARG; }
     p->opt = bo;
     p->variants = (int)opts->variants;
     p->device = opts->device;
-    // every attestation of an attester must have come through one process: then the summed figures of this process's
-    // attesters are its own
-    for (uint32_t i = 0; i < n; ++i)
-        if (p->local.out_deg[i] != 0 && (out_degree[i] != p->local.out_deg[i] || row_sum[i] != p->sums.u64[i])) {
-            set_error("the attestations of one attester were given to more than one process");
-            return ET_E_INVALID_ARG;
-        }
+    if (value_max < p->local.value_max) {
+        // a maximum that is too small would pick byte-wide edge records for opinions that do not fit them
+        set_error("value_max is smaller than this process's own largest opinion: take the maximum over all processes");
+        return ET_E_INVALID_ARG;
+    }
+    // every attestation of an attester must have come through one process: then the summed count of this process's
+    // attesters is its own (zero-valued attestations count too: an attester whose opinions here sum to zero is dangling here
+    // but must not have other opinions elsewhere)
+    {
+        std::vector<uint32_t> mine(n);
+        count_attested(p, mine.data());
+        for (uint32_t i = 0; i < n; ++i)
+            if (mine[i] != 0 && (attested[i] != mine[i] || out_degree[i] != p->local.out_deg[i] || row_sum[i] != p->sums.u64[i])) {
+                set_error("the attestations of one attester were given to more than one process");
+                return ET_E_INVALID_ARG;
+            }
+    }
     HostGraph& g = p->pc.g;
     const uint8_t* member = p->member.empty() ? nullptr : p->member.data();
     auto is_member = [&](uint32_t i) { return member ? member[i] != 0 : true; };
@@ -188,20 +215,71 @@ int et_dplan_info_get(const et_dplan* p, et_graph_info* info) {
     info->n = h.n; info->n_valid = h.n_valid; info->n_dangling = h.geo.n_dangling;
     info->n_seg = h.geo.n_seg; info->seg = h.geo.seg; info->nnz = h.nnz;
     info->rows_cap = h.geo.rows_cap; info->nd_cap = h.geo.nd_cap;
-    info->vec_len = (uint64_t)h.geo.n_seg * h.geo.seg_stride();
+    info->vec_len = h.geo.vec_len;            // with a gather vector: the own block only until et_dplan_needs has run
+    info->full_len = (uint64_t)h.geo.n_seg * h.geo.seg_stride();
+    info->gather = h.geo.compact;
     info->n_chunks = h.geo.n_chunks; info->chunk_rows = h.geo.chunk_rows;
     return ET_OK;
 }
 
-static int lay_out(et_dplan* p, bool for_device) {
-    if (p->stage != 2) { set_error("finish follows set_global_stats and the records"); return ET_E_INVALID_ARG; }
-    if (for_device) xcd_cost_factors(p->device, p->opt.xcd_cost);
+// stage 2 -> 3: no more records; sorts them and finds the rows of the other shares this share cites
+static int seal_records(et_dplan* p) {
+    if (p->stage == 3) return ET_OK;
+    if (p->stage != 2) { set_error("the records are complete between set_global_stats and finish"); return ET_E_INVALID_ARG; }
     p->out_src = std::vector<uint32_t>(); p->out_row = std::vector<uint32_t>(); p->out_val = std::vector<uint32_t>();
     std::string err;
-    int rc = plan_segment_from_records(p->pc.g, p->opt, p->opt.seg, p->in_src, p->in_row, p->in_val, err);
+    int rc = records_to_needs(p->pc.g, p->opt.seg, p->in_src, p->in_row, p->in_val, &p->sorted, err);
     if (rc) { set_error(err); return rc; }
     p->in_src = std::vector<uint32_t>(); p->in_row = std::vector<uint32_t>(); p->in_val = std::vector<uint32_t>();
+    p->told.assign(p->pc.g.geo.n_seg, 0);
+    p->told[p->opt.seg] = 1;
     p->stage = 3;
+    return ET_OK;
+}
+
+int et_dplan_needs(et_dplan* p, uint32_t share, uint64_t* count, const uint32_t** rows) {
+    if (!p || !count || !rows) return ET_E_INVALID_ARG;
+    int rc = seal_records(p);
+    if (rc) return rc;
+    if (share >= p->pc.g.geo.n_seg) return ET_E_OUT_OF_RANGE;
+    *count = p->pc.g.need[share].size();
+    *rows = p->pc.g.need[share].data();
+    return ET_OK;
+}
+
+int et_dplan_add_wanted(et_dplan* p, uint32_t share, uint64_t count, const uint32_t* rows) {
+    if (!p || (count && !rows)) return ET_E_INVALID_ARG;
+    int rc = seal_records(p);
+    if (rc) return rc;
+    HostGraph& g = p->pc.g;
+    if (share >= g.geo.n_seg) return ET_E_OUT_OF_RANGE;
+    if (share == p->opt.seg || !g.geo.compact) {
+        if (count == 0) return ET_OK;
+        set_error("this share packs nothing for that share");
+        return ET_E_INVALID_ARG;
+    }
+    for (uint64_t k = 0; k < count; ++k) if (rows[k] >= g.geo.rows_cap) { set_error("cited row out of range"); return ET_E_OUT_OF_RANGE; }
+    g.send[share].assign(rows, rows + count);
+    p->told[share] = 1;
+    return ET_OK;
+}
+
+static int lay_out(et_dplan* p, bool for_device) {
+    int rc = seal_records(p);
+    if (rc) return rc;
+    HostGraph& g = p->pc.g;
+    if (g.geo.compact) {
+        for (uint32_t c = 0; c < g.geo.n_seg; ++c)
+            if (!p->told[c]) { set_error("et_dplan_add_wanted has not been called for every other share"); return ET_E_INVALID_ARG; }
+        g.send_known = true;
+    }
+    if (for_device) xcd_cost_factors(p->device, p->opt.xcd_cost);
+    std::string err;
+    rc = plan_segment_from_sorted(g, p->opt, p->sorted, err);
+    if (rc) { set_error(err); return rc; }
+    free_sorted_records(p->sorted);
+    p->sorted = nullptr;
+    p->stage = 4;
     return ET_OK;
 }
 

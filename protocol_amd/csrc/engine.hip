@@ -101,12 +101,12 @@ __global__ void k_init_f64(Geometry g, double initial, double d0, double* __rest
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t stride = g.seg_stride();
     if (i >= stride) return;
-    const size_t p = (size_t)g.seg * stride + i;
+    const size_t p = (size_t)g.own_off + i;
     double v = 0.0;
     if (i < g.rows_cap) {
         v = row_is_member(g, i) ? initial : 0.0;
         if (own) own[i] = v;
-        if (scale) v *= scale[p];
+        if (scale) v *= scale[i];
     } else if (i == g.rows_cap) v = d0;
     x[p] = v;
 }
@@ -115,12 +115,12 @@ __global__ void k_init_fr(Geometry g, U256 initial, U256 d0, uint4* __restrict__
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t stride = g.seg_stride();
     if (i >= stride) return;
-    const size_t p = (size_t)g.seg * stride + i;
+    const size_t p = (size_t)g.own_off + i;
     U256 v = u256_zero();
     if (i < g.rows_cap) {
         if (row_is_member(g, i)) v = initial;
         if (own) u256_store(own + 2 * (size_t)i, v);
-        if (scale) v = fr_mul_redc288(v, u256_load(scale + 2 * p));
+        if (scale) v = fr_mul_redc288(v, u256_load(scale + 2 * (size_t)i));
     } else if (i == g.rows_cap) v = d0;
     u256_store(x + 2 * p, v);
 }
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     const uint32_t b = blockIdx.x;
     const uint32_t RB = a.geo.f64_rb;
     const uint32_t stride = a.geo.seg_stride();
-    const size_t my_base = (size_t)a.geo.seg * stride;
+    const size_t my_base = a.geo.own_off;
     const double* __restrict__ xr = a.x;
     const VT* __restrict__ wr = static_cast<const VT*>(a.w);
     const bool first_phase = !PHASED || a.phase == 0, last_phase = !PHASED || a.phase + 1 == a.n_phases;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
         dv[u] = 0.0;
         if (t < d_total) {
             const uint32_t sg = t / a.geo.nd_cap, k = t - sg * a.geo.nd_cap;
-            dv[u] = xr[(size_t)sg * stride + a.geo.rows_cap + k];
+            dv[u] = xr[(size_t)a.geo.dtail[sg] + k];
         }
     }
     // The rows' epilogue needs, per row, its group entry and then the old score and the factor: two dependent trips to
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
             // raw form: a peer with opinions keeps no plain score between iterations (its old one is the exchanged entry
             // divided by the factor); a peer without has factor zero and keeps its plain score in `own`
             pold[u] = RAW && row_is_dangling(a.geo, row) ? a.own[row] : xr[my_base + row];
-            if (RAW) psc[u] = a.scale[my_base + row];
+            if (RAW) psc[u] = a.scale[row];
             if (HAS_ALPHA) ppt[u] = a.pretrust[my_base + row];
         }
     }
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     double D = (dv[0] + dv[1]) + (dv[2] + dv[3]);
     for (uint32_t t = lane + 256; t < d_total; t += 64) {
         const uint32_t sg = t / a.geo.nd_cap, k = t - sg * a.geo.nd_cap;
-        D += xr[(size_t)sg * stride + a.geo.rows_cap + k];
+        D += xr[(size_t)a.geo.dtail[sg] + k];
     }
     D = wave_sum_f64(D);
     const double dterm = D * a.inv_nm1;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
                 if (live[u]) { old[u] = pold[u]; sc[u] = psc[u]; pt[u] = ppt[u]; }
             } else if (live[u]) {
                 old[u] = RAW && dang[u] ? a.own[row[u]] : xr[my_base + row[u]];
-                if (RAW) sc[u] = a.scale[my_base + row[u]];
+                if (RAW) sc[u] = a.scale[row[u]];
                 if (HAS_ALPHA) pt[u] = a.pretrust[my_base + row[u]];
             }
             if (RAW && live[u] && !dang[u]) old[u] = old[u] / sc[u];
@@ -424,7 +424,7 @@ struct StepArgsFr {
 // caller's allocation happened to hold.
 ET_DEV void fr_zero_unused_tail(uint4* __restrict__ y, const Geometry& geo, uint32_t written, uint32_t threads) {
     if (blockIdx.x != 0) return;
-    const size_t tail = (size_t)geo.seg * geo.seg_stride() + geo.rows_cap;
+    const size_t tail = (size_t)geo.own_off + geo.rows_cap;
     for (uint32_t k = written + threadIdx.x; k < geo.nd_cap; k += threads) u256_store(y + 2 * (tail + k), u256_zero());
 }
 
@@ -453,7 +453,6 @@ ET_DEV void fr_dangling_mass(const uint4* __restrict__ x, const Geometry& geo, c
         }
         return;
     }
-    const uint32_t stride = geo.seg_stride();
     Acc d = acc_zero();
     const uint32_t total = geo.n_seg * geo.nd_cap;
     for (uint32_t t0 = lane; t0 < total; t0 += 256) {     // four entries per lane in flight
@@ -464,7 +463,7 @@ ET_DEV void fr_dangling_mass(const uint4* __restrict__ x, const Geometry& geo, c
             p[u] = u256_zero();
             if (t < total) {
                 const uint32_t sg = t / geo.nd_cap, k = t - sg * geo.nd_cap;
-                p[u] = u256_load(x + 2 * ((size_t)sg * stride + geo.rows_cap + k));
+                p[u] = u256_load(x + 2 * ((size_t)geo.dtail[sg] + k));
             }
         }
 #pragma unroll
@@ -534,7 +533,7 @@ __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr(StepArgsFr a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t stride = a.geo.seg_stride();
-    const size_t my_base = (size_t)a.geo.seg * stride;
+    const size_t my_base = a.geo.own_off;
     fr_zero_unused_tail(a.y, a.geo, a.n_dslots, WPB_FR * 64);
     // The first wavefront prepares the dangling mass while the others already walk their first slice.  Every
     // wavefront of the workgroup stays alive (one without a work item walks no slice) and all of them meet at
@@ -605,7 +604,7 @@ __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr_raw(StepArgsFr a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t stride = a.geo.seg_stride();
-    const size_t my_base = (size_t)a.geo.seg * stride;
+    const size_t my_base = a.geo.own_off;
     fr_zero_unused_tail(a.y, a.geo, a.n_dslots, WPB_FR * 64);
     // The first wavefront prepares the dangling mass while the others already walk their first slice.  Every
     // wavefront of the workgroup stays alive (one without a work item walks no slice) and all of them meet at
@@ -679,7 +678,7 @@ __global__ __launch_bounds__(WPB_FR * 64) void k_step_fr_raw(StepArgsFr a) {
             U256 v = acc_redc288(full);
             u256_store(a.own + 2 * (size_t)row, v);
             // a dangling peer has no out-edges: its exchanged entry is never gathered
-            U256 out = a.final_step ? v : (dang ? u256_zero() : fr_mul_redc288(v, u256_load(a.scale + 2 * (my_base + row))));
+            U256 out = a.final_step ? v : (dang ? u256_zero() : fr_mul_redc288(v, u256_load(a.scale + 2 * (size_t)row)));
             u256_store(a.y + 2 * (my_base + row), out);
             changed += u256_eq(v, old) ? 0u : 1u;
             tot = fr_add(tot, v);
@@ -773,7 +772,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x, RB = a.geo.fr_rb;
     const uint32_t stride = a.geo.seg_stride();
-    const size_t my_base = (size_t)a.geo.seg * stride;
+    const size_t my_base = a.geo.own_off;
     uint32_t* const top_l = reinterpret_cast<uint32_t*>(colsum_l + 4 * (size_t)RB);   // COMPACT: limb 8 of every row
     const bool first_phase = !PHASED || a.phase == 0, last_phase = !PHASED || a.phase + 1 == a.n_phases;
     const uint32_t lds_words = COMPACT ? 4 * RB + RB / 2 : 8 * RB;                     // RB is a multiple of 16
@@ -991,7 +990,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             }
             traw.v[9] += (uint32_t)c;
         }
-        const U256 xs = fr_mul9_redc288(t, u256_load(a.scale288 + 2 * (my_base + row)));
+        const U256 xs = fr_mul9_redc288(t, u256_load(a.scale288 + 2 * (size_t)row));
         const U256 old = u256_load(a.x + 2 * (my_base + row));
         changed += u256_eq(xs, old) ? 0u : 1u;
         if (a.final_step) {
@@ -1096,6 +1095,16 @@ __global__ void k_unpermute_fr(const uint32_t* __restrict__ pos, const uint4* __
     U256 v = p == 0xFFFFFFFFu ? u256_zero() : u256_load(x + 2 * (size_t)p);
     u256_store(out + 2 * (size_t)i, v);
 }
+// Gather vector: the entries of this share's own block that another share cites, in the order it asked for.
+// One thread per 8 bytes (f64) or per 16-byte half of a field element.
+__global__ void k_pack_f64(const double* __restrict__ own, const uint32_t* __restrict__ idx, double* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = own[idx[i]];
+}
+__global__ void k_pack_fr(const uint4* __restrict__ own, const uint32_t* __restrict__ idx, uint4* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * n) out[i] = own[2 * (size_t)idx[i >> 1] + (i & 1)];
+}
 // a * b mod r through the same multiply-accumulate and reduction the step kernel uses:
 // (a * 2^576 * 2^-288) * b * 2^-288.  `c576` = 2^576 mod r.
 __global__ void k_fr_mul_test(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ out, U256 c576, uint32_t n) {
@@ -1134,7 +1143,7 @@ static int dev_upload(T** p, const std::vector<T>& v, uint64_t& total) {
 
 DeviceGraph::~DeviceGraph() {
     if (device >= 0) (void)hipSetDevice(device);
-    void* ptrs[] = {d_fb_rec, d_fb_cbase, d_fb_cptr, d_bk_ptr, d_bk_grp, d_bk_col, d_bk_row, d_bk_w, d_bk_rec, d_bk_cbase, d_bk_cptr, d_fb_ptr, d_fb_grp, d_fb_col, d_fb_row, d_fb_val, d_work, d_slices, d_col, d_val, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
+    void* ptrs[] = {d_send_idx, d_fb_rec, d_fb_cbase, d_fb_cptr, d_bk_ptr, d_bk_grp, d_bk_col, d_bk_row, d_bk_w, d_bk_rec, d_bk_cbase, d_bk_cptr, d_fb_ptr, d_fb_grp, d_fb_col, d_fb_row, d_fb_val, d_work, d_slices, d_col, d_val, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
                     d_chg_part, d_stat_out, d_bk_phase, d_fb_phase, d_f64_acc, d_fr_acc, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust, d_scale64, d_scale_fr, d_fb_scale, own64, own_fr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* e : ev_begin) (void)hipEventDestroy((hipEvent_t)e);
@@ -1295,8 +1304,10 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     if ((rc = dev_upload(&g->d_col, h.col, tot))) return rc;
     if ((rc = dev_upload(&g->d_pos, h.pos_of_ext, tot))) return rc;
     const size_t slots = (size_t)h.n_steps * 64;
-    const size_t vec_len = (size_t)h.geo.n_seg * h.geo.seg_stride();
+    const size_t vec_len = h.geo.vec_len;                                  // entries of the vectors the steps take
+    const size_t stride = h.geo.seg_stride(), full_len = (size_t)h.geo.n_seg * stride;
     g->vec_len = vec_len;
+    g->full_len = full_len;
     sweep_barriers(h, *g);
     // raw form: opinions stay as they are (one byte each when they fit), the source factors stay
     // resident; weighted form: opinions and factors are only needed until the weights are computed
@@ -1319,9 +1330,20 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
         *dst = p;
         return r;
     };
-    if ((rc = dev_upload(&g->d_scale64, h.scale_f64, tot))) return rc;
-    if ((rc = dev_alloc(&g->d_scale_fr, vec_len * 2, tot))) return rc;
-    HIP_TRY(hipMemcpy(g->d_scale_fr, h.scale_fr.data(), vec_len * 32, hipMemcpyHostToDevice));
+    // the factors of this share's own rows stay resident (a step scales the rows it owns), indexed by local row
+    if (h.scale_f64.size() != full_len || h.scale_fr.size() != full_len) { set_error("internal: factor arrays"); return ET_E_INVALID_ARG; }
+    const size_t own_first = (size_t)h.geo.seg * stride;
+    if ((rc = dev_alloc(&g->d_scale64, stride, tot)) || (rc = dev_alloc(&g->d_scale_fr, stride * 2, tot))) return rc;
+    HIP_TRY(hipMemcpy(g->d_scale64, h.scale_f64.data() + own_first, stride * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g->d_scale_fr, h.scale_fr.data() + own_first, stride * 32, hipMemcpyHostToDevice));
+    // weighted form only: every source's factor, by position, until the weights are computed
+    double* d_scale64_all = nullptr;
+    uint4* d_scale_fr_all = nullptr;
+    auto free_all = [&]() { if (d_scale64_all) (void)hipFree(d_scale64_all); if (d_scale_fr_all) (void)hipFree(d_scale_fr_all); d_scale64_all = nullptr; d_scale_fr_all = nullptr; };
+    if (!g->raw) {
+        if ((rc = dev_upload(&d_scale64_all, h.scale_f64, tmp_bytes)) || (rc = dev_alloc(&d_scale_fr_all, full_len * 2, tmp_bytes))) { free_all(); return rc; }
+        HIP_TRY(hipMemcpy(d_scale_fr_all, h.scale_fr.data(), full_len * 32, hipMemcpyHostToDevice));
+    }
     const unsigned nb = (unsigned)((slots + 255) / 256);
     const bool can_pack = g->raw && g->val_bytes == 1 && vec_len <= 0xFFFFFFFFull && h.geo.n_chunks == 1;
     if (g->variants & ET_VARIANT_F64) {
@@ -1353,7 +1375,7 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
                 uint4* d_bv = nullptr;
                 if ((rc = dev_alloc(&d_bv, ne * 2, tmp_bytes))) return rc;
                 HIP_TRY(hipMemcpy(d_bv, h.bk_val_fr.data(), ne * 32, hipMemcpyHostToDevice));
-                hipLaunchKernelGGL(k_normalise_f64_fr, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, 0, g->d_bk_col, d_bv, g->d_scale64, w, ne, h.geo);
+                hipLaunchKernelGGL(k_normalise_f64_fr, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, 0, g->d_bk_col, d_bv, d_scale64_all, w, ne, h.geo);
                 HIP_TRY(hipDeviceSynchronize());
                 (void)hipFree(d_bv);
             }
@@ -1361,11 +1383,12 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
         if (h.geo.n_chunks > 1) {
             if ((rc = dev_upload(&g->d_bk_phase, h.bk_phase, tot)) || (rc = dev_alloc(&g->d_f64_acc, (size_t)h.geo.f64_blocks * h.geo.f64_rb, tot))) return rc;
         }
-        for (int i = 0; i < 2; ++i) {
+        // the graph's own vectors serve the whole-graph runs (run_f64); a share of several steps on its driver's vectors
+        for (int i = 0; i < 2 && h.geo.n_seg == 1; ++i) {
             if ((rc = dev_alloc(&g->vx[i], vec_len, tot))) return rc;
             HIP_TRY(hipMemset(g->vx[i], 0, vec_len * sizeof(double)));
         }
-        if ((rc = dev_alloc(&g->out_f64, h.n, tot)) || (rc = dev_alloc(&g->d_res_part, (size_t)STATS_RING * g->n_f64_parts, tot)) ||
+        if ((h.geo.n_seg == 1 && (rc = dev_alloc(&g->out_f64, h.n, tot))) || (rc = dev_alloc(&g->d_res_part, (size_t)STATS_RING * g->n_f64_parts, tot)) ||
             (rc = dev_alloc(&g->d_sum_part, (size_t)STATS_RING * g->n_f64_parts, tot))) return rc;
     }
     if (g->variants & ET_VARIANT_FR) {
@@ -1377,11 +1400,11 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
             if ((rc = dev_alloc(&d_valfr, slots * 2, tmp_bytes))) return rc;
             if (slots) HIP_TRY(hipMemcpy(d_valfr, h.val_fr.data(), slots * 32, hipMemcpyHostToDevice));
             if ((rc = dev_alloc(&g->d_wlo, slots, tot)) || (rc = dev_alloc(&g->d_whi, slots, tot))) { free_tmp(); return rc; }
-            if (slots) hipLaunchKernelGGL(k_normalise_fr_fr, dim3(nb), dim3(256), 0, 0, g->d_col, d_valfr, g->d_scale_fr, g->d_wlo, g->d_whi, slots, h.geo);
+            if (slots) hipLaunchKernelGGL(k_normalise_fr_fr, dim3(nb), dim3(256), 0, 0, g->d_col, d_valfr, d_scale_fr_all, g->d_wlo, g->d_whi, slots, h.geo);
             HIP_TRY(hipDeviceSynchronize());
             free_tmp();
         }
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2 && h.geo.n_seg == 1; ++i) {
             if ((rc = dev_alloc(&g->fx[i], vec_len * 2, tot))) return rc;
             HIP_TRY(hipMemset(g->fx[i], 0, vec_len * 32));
         }
@@ -1407,14 +1430,42 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
                                     (const void*)k_step_fr_blocked<true, true>, (const void*)k_step_fr_blocked<false, true>};
             for (const void* f : sweeps) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
             // the sweep multiplies unreduced row sums by inv(sum) * 2^288 (the resident factors carry 2^576)
-            if ((rc = dev_alloc(&g->d_fb_scale, vec_len * 2, tot))) return rc;
-            hipLaunchKernelGGL(k_scale_288, dim3((unsigned)((vec_len + 255) / 256)), dim3(256), 0, 0, g->d_scale_fr, g->d_fb_scale, vec_len);
+            if ((rc = dev_alloc(&g->d_fb_scale, stride * 2, tot))) return rc;
+            hipLaunchKernelGGL(k_scale_288, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, 0, g->d_scale_fr, g->d_fb_scale, stride);
             HIP_TRY(hipDeviceSynchronize());
         }
-        if ((rc = dev_alloc(&g->out_fr, (size_t)h.n * 2, tot)) || (rc = dev_alloc(&g->d_frsum_part, (size_t)STATS_RING * g->n_fr_parts * 2, tot)) ||
+        if ((h.geo.n_seg == 1 && (rc = dev_alloc(&g->out_fr, (size_t)h.n * 2, tot))) || (rc = dev_alloc(&g->d_frsum_part, (size_t)STATS_RING * g->n_fr_parts * 2, tot)) ||
             (rc = dev_alloc(&g->d_chg_part, (size_t)STATS_RING * g->n_fr_parts, tot))) return rc;
     }
     if ((rc = dev_alloc(&g->d_stat_out, 64, tot))) return rc;
+    // the exchange: what this share sends to and receives from every other share
+    {
+        const Geometry& geo = h.geo;
+        const uint32_t own_len = geo.seg_stride();
+        if (geo.compact) {
+            if (!h.send_known) { set_error("the rows the other shares cite are not known"); return ET_E_INVALID_ARG; }
+            std::vector<uint32_t> idx;
+            for (uint32_t c = 0; c < geo.n_seg; ++c) {
+                if (c == geo.seg) continue;
+                g->send_off[c] = (uint32_t)idx.size();
+                idx.insert(idx.end(), h.send[c].begin(), h.send[c].end());
+                for (uint32_t k = 0; k < geo.nd_cap; ++k) idx.push_back(geo.rows_cap + k);
+                g->send_cnt[c] = (uint32_t)idx.size() - g->send_off[c];
+                g->recv_off[c] = h.blk_off[c];
+                g->recv_cnt[c] = (uint32_t)h.need[c].size() + geo.nd_cap;
+            }
+            for (uint32_t v : idx) if (v >= own_len) { set_error("internal: packed entry outside the own block"); return ET_E_INVALID_ARG; }
+            g->send_total = idx.size();
+            if ((rc = dev_upload(&g->d_send_idx, idx, tot))) return rc;
+        } else {
+            for (uint32_t c = 0; c < geo.n_seg; ++c) {
+                if (c == geo.seg) continue;
+                g->send_off[c] = 0; g->send_cnt[c] = own_len;
+                g->recv_off[c] = c * own_len; g->recv_cnt[c] = own_len;
+            }
+            g->send_total = geo.n_seg > 1 ? own_len : 0;
+        }
+    }
     // the LDS accumulators may exceed the 64 KiB a kernel may use without opting in
     {
         const int lds_max = 160 * 1024 - 1024;
@@ -1428,6 +1479,7 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     free_tmp();
+    free_all();
     *out = g.release();
     return ET_OK;
 }
@@ -1569,6 +1621,20 @@ int DeviceGraph::stats_fr(uint32_t iteration, hipStream_t st, et_iter_stats* out
     std::memset(out, 0, sizeof(*out));
     std::memcpy(out->sum.b, h, 32);
     std::memcpy(&out->changed, h + 32, 8);
+    return ET_OK;
+}
+
+int DeviceGraph::pack(const void* y, void* send, size_t elem, hipStream_t st) {
+    if (!y || !send || (elem != 8 && elem != 32)) return ET_E_INVALID_ARG;
+    if (!geo.compact) {       // position order: a share's segment is what it sends
+        if (send_total) HIP_TRY(hipMemcpyAsync(send, static_cast<const char*>(y) + (size_t)geo.own_off * elem, send_total * elem, hipMemcpyDeviceToDevice, st));
+        return ET_OK;
+    }
+    const uint32_t n = (uint32_t)send_total;
+    if (n == 0) return ET_OK;
+    if (elem == 8) hipLaunchKernelGGL(k_pack_f64, dim3((n + 255) / 256), dim3(256), 0, st, static_cast<const double*>(y) + geo.own_off, d_send_idx, static_cast<double*>(send), n);
+    else hipLaunchKernelGGL(k_pack_fr, dim3((2 * n + 255) / 256), dim3(256), 0, st, static_cast<const uint4*>(y) + 2 * (size_t)geo.own_off, d_send_idx, static_cast<uint4*>(send), n);
+    HIP_TRY(hipGetLastError());
     return ET_OK;
 }
 

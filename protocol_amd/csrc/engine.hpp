@@ -28,7 +28,8 @@ struct DeviceGraph {
     uint32_t n_slices = 0, n_work = 0, n_dangling_local = 0;
     uint32_t n_dslots = 0;            // partial-sum slots the row-per-lane exact kernels write (their dangling work items)
     Geometry geo{};
-    size_t vec_len = 0;
+    size_t vec_len = 0;               // entries of the vectors the steps read and write (geo.vec_len)
+    size_t full_len = 0;              // n_seg * seg_stride: the position-order vector the un-permutation reads
     uint64_t device_bytes = 0;
     std::vector<uint32_t> pos_of_ext;
     FrRaw inv_nm1_w{};
@@ -94,6 +95,13 @@ struct DeviceGraph {
     double* out_f64 = nullptr;
     uint4* out_fr = nullptr;
     double* d_pretrust = nullptr;
+    // Gather vector (geo.compact): after a step this share packs, for every other share c, the entries of its own block that
+    // c cites followed by its partial sums -- send_cnt[c] entries at send_off[c] of the pack buffer, picked by d_send_idx --
+    // and receives recv_cnt[p] entries from share p at recv_off[p] of the vector.  Position order: every share sends its whole
+    // segment (send_off 0) and receives segment p at p * seg_stride.
+    uint32_t* d_send_idx = nullptr;
+    uint32_t send_off[8] = {}, send_cnt[8] = {}, recv_off[8] = {}, recv_cnt[8] = {};
+    uint64_t send_total = 0;
     // ring of HIP event pairs bracketing the iteration launches of timed runs
     static const uint32_t EVENT_RING = 1024;
     std::vector<void*> ev_begin, ev_end;
@@ -114,6 +122,8 @@ struct DeviceGraph {
     int stats_fr(uint32_t iteration, hipStream_t st, et_iter_stats* out);
     int run_f64(uint32_t iters, double initial, double alpha, hipStream_t st, bool record);
     int run_fr(uint32_t iters, uint64_t lo, uint64_t hi, hipStream_t st, bool record);
+    // copies the entries the other shares cite out of the own block of y into `send` (elem = 8 or 32 bytes per entry)
+    int pack(const void* y, void* send, size_t elem, hipStream_t st);
     int record_begin(hipStream_t st);
     int record_end(hipStream_t st);
     int event_times(float* total_ms, uint32_t* pairs);

@@ -22,6 +22,12 @@
 // GPU), each `rows_cap` row entries followed by `nd_cap` entries holding that GPU's partial sums of
 // the score mass of dangling peers (peers whose filtered row is empty, native.rs:263-278).  An
 // in-place all-gather of the segments therefore carries vector and partial sums in one message.
+//
+// Several GPUs, integer opinions: a share does not keep the other shares' whole segments.  Its vectors
+// hold its own segment first and then, per other share p, only the entries of p's rows that its own
+// rows cite (in the order it asked for) followed by p's partial sums: the "gather vector".  The exchange
+// sends every share exactly the entries it cites, and the gathered vector shrinks from all peers to
+// the cited ones.  A source index in an edge record is then the entry's index in the gather vector.
 #pragma once
 #include <cstdint>
 
@@ -95,7 +101,43 @@ struct Geometry {
     // the rest and the partial-sum tail), and an iteration runs as n_chunks launches, launch q over the edges whose
     // source lies in piece q of ANY segment; a workgroup's edge list is sorted by (piece, position).  1 = off.
     uint32_t n_chunks, chunk_rows;
+    // Where this share's own segment and every share's partial sums sit in the vectors the steps read and write.
+    // Position order (compact == 0): own_off = seg * seg_stride(), dtail[p] = p * seg_stride() + rows_cap,
+    // vec_len = n_seg * seg_stride().  Gather vector (compact == 1): own_off = 0, block p != seg holds the cited
+    // entries of share p followed by its partial sums at dtail[p]; vec_len = entries of the gather vector.
+    uint32_t compact, own_off, vec_len;
+    uint32_t dtail[8];
     ET_HD uint32_t seg_stride() const { return rows_cap + nd_cap; }
+    // this share's view of the layout; with a gather vector the other shares' blocks follow once the cited rows are known
+    // (set_gather_blocks)
+    ET_HD void set_share(uint32_t s) {
+        seg = s;
+        for (uint32_t p = 0; p < 8; ++p) dtail[p] = 0u;
+        if (compact) {
+            own_off = 0;
+            vec_len = seg_stride();
+            dtail[s] = rows_cap;
+            return;
+        }
+        own_off = s * seg_stride();
+        vec_len = n_seg * seg_stride();
+        for (uint32_t p = 0; p < n_seg; ++p) dtail[p] = p * seg_stride() + rows_cap;
+    }
+    // gather vector: block p (p != seg, ascending) = cited[p] entries of share p's rows, then its nd_cap partial sums;
+    // blk_off[p] receives the block's first entry
+    ET_HD void set_gather_blocks(const uint32_t* cited, uint32_t* blk_off) {
+        uint32_t at = seg_stride();
+        own_off = 0;
+        for (uint32_t p = 0; p < 8; ++p) { dtail[p] = 0u; blk_off[p] = 0u; }
+        dtail[seg] = rows_cap;
+        for (uint32_t p = 0; p < n_seg; ++p) {
+            if (p == seg) continue;
+            blk_off[p] = at;
+            dtail[p] = at + cited[p];
+            at = dtail[p] + nd_cap;
+        }
+        vec_len = at;
+    }
     ET_HD uint32_t chunk_of_local(uint32_t local) const {
         const uint32_t q = local / chunk_rows;
         return q < n_chunks ? q : n_chunks - 1;

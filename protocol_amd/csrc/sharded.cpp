@@ -7,6 +7,12 @@
 // one all-gather per iteration, the only exchange on the path.  A segment carries its rows' entries and,
 // in its tail, the GPU's partial sums of the dangling peers' score mass, so no second collective is needed.
 //
+// Integer opinions (the production case): a GPU does not keep the other GPUs' whole segments but a gather vector --
+// its own block, then only the entries of the other GPUs' rows that its own rows cite (layout.hpp).  After a step
+// every GPU packs what each other GPU cites into a send buffer (DeviceGraph::pack) and the exchange is an
+// all-to-all of those pieces: grouped ncclSend / ncclRecv, or pulls from the producers' send buffers.  The result is
+// assembled once, at the end, from the GPUs' own blocks.
+//
 // Exchange.  RCCL's all-gather (in place, one group call over the GPUs' communicators) when the devices are
 // distinct; librccl is loaded at run time, so the library itself has no link-time dependency on it.  When
 // the same device is listed more than once (a rehearsal of the N-share layout on fewer GPUs: RCCL refuses two
@@ -54,6 +60,8 @@ struct Rccl {
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -73,10 +81,12 @@ Rccl& rccl() {
     r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.handle, "ncclCommInitAll");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
     r.AllGather = (decltype(r.AllGather))dlsym(r.handle, "ncclAllGather");
+    r.Send = (decltype(r.Send))dlsym(r.handle, "ncclSend");
+    r.Recv = (decltype(r.Recv))dlsym(r.handle, "ncclRecv");
     r.GroupStart = (decltype(r.GroupStart))dlsym(r.handle, "ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.handle, "ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
-    r.ok = r.CommInitAll && r.CommDestroy && r.AllGather && r.GroupStart && r.GroupEnd && r.GetErrorString;
+    r.ok = r.CommInitAll && r.CommDestroy && r.AllGather && r.Send && r.Recv && r.GroupStart && r.GroupEnd && r.GetErrorString;
     if (!r.ok) r.why = "librccl lacks an entry point";
     return r;
 }
@@ -104,7 +114,10 @@ struct et_sharded {
     std::vector<void*> staging;               // chunked exchange over RCCL: world x (longest piece) per share
     uint32_t n_chunks = 1;
     std::vector<hipEvent_t> done;             // share r's segment of the vector just written is complete
-    std::vector<void*> vec[2];                // per share: two full-length vectors, sized for the widest variant built
+    std::vector<void*> vec[2];                // per share: two vectors (g[r]->vec_len entries), sized for the widest variant built
+    bool gather = false;                      // the shares' vectors are gather vectors
+    std::vector<void*> sendbuf[2];            // gather vectors: what share r packed for the others after writing vec[b][r]
+    void* full = nullptr;                     // gather vectors: the result in position order, on the first share's device
     std::vector<double*> pretrust;            // per share, f64 with alpha != 0 only
     std::vector<ncclComm_t> comm;
     size_t vec_len = 0, seg_stride = 0;
@@ -120,6 +133,8 @@ struct et_sharded {
         for (uint32_t r = 0; r < world; ++r) {
             if (r < device.size()) (void)hipSetDevice(device[r]);
             for (int b = 0; b < 2; ++b) if (r < vec[b].size() && vec[b][r]) (void)hipFree(vec[b][r]);
+            for (int b = 0; b < 2; ++b) if (r < sendbuf[b].size() && sendbuf[b][r]) (void)hipFree(sendbuf[b][r]);
+            if (r == 0 && full) (void)hipFree(full);
             if (r < pretrust.size() && pretrust[r]) (void)hipFree(pretrust[r]);
             if (r < done.size() && done[r]) (void)hipEventDestroy(done[r]);
             for (uint32_t q = 0; q < n_chunks; ++q)
@@ -135,6 +150,7 @@ struct et_sharded {
     // Every share receives the other shares' segments of buffer `b` (elements of `elem` bytes).
     int exchange_segments(int b, size_t elem) {
         if (world == 1 && exchange != ET_EXCHANGE_RCCL) return ET_OK;   // (one rank over RCCL: the call is made all the same)
+        if (gather) return exchange_cited(b, elem);
         const size_t seg_bytes = seg_stride * elem;
         if (exchange == ET_EXCHANGE_RCCL) {
             RCCL_TRY(rccl().GroupStart());
@@ -166,6 +182,75 @@ struct et_sharded {
         // a share may overwrite its segment of the OTHER buffer in its next step only after every share has pulled
         // that buffer's previous contents; the pulls above are ordered before each puller's own next step, and a share's
         // step after next needs the pullers' next segments first, so the chain of events already enforces it
+        return ET_OK;
+    }
+
+    // Gather vectors: every share packs what the others cite of the block it has just written into vec[b], and every share
+    // receives its pieces at the blocks of its own vec[b].
+    int exchange_cited(int b, size_t elem) {
+        int rc;
+        for (uint32_t r = 0; r < world; ++r) {
+            HIP_TRY_S(hipSetDevice(device[r]));
+            if ((rc = g[r]->pack(vec[b][r], sendbuf[b][r], elem, stream[r]))) return rc;
+        }
+        if (exchange == ET_EXCHANGE_RCCL) {
+            RCCL_TRY(rccl().GroupStart());
+            for (uint32_t r = 0; r < world; ++r)
+                for (uint32_t c = 0; c < world; ++c) {
+                    if (c == r) continue;
+                    ncclResult_t e = rccl().Send(static_cast<char*>(sendbuf[b][r]) + (size_t)g[r]->send_off[c] * elem, (size_t)g[r]->send_cnt[c] * elem,
+                                                 ncclChar, (int)c, comm[r], stream[r]);
+                    if (e == ncclSuccess)
+                        e = rccl().Recv(static_cast<char*>(vec[b][r]) + (size_t)g[r]->recv_off[c] * elem, (size_t)g[r]->recv_cnt[c] * elem,
+                                        ncclChar, (int)c, comm[r], stream[r]);
+                    if (e != ncclSuccess) {
+                        (void)rccl().GroupEnd();
+                        set_error(std::string("ncclSend/ncclRecv: ") + rccl().GetErrorString(e));
+                        return ET_E_RCCL;
+                    }
+                }
+            RCCL_TRY(rccl().GroupEnd());
+            return ET_OK;
+        }
+        for (uint32_t r = 0; r < world; ++r) {
+            HIP_TRY_S(hipSetDevice(device[r]));
+            HIP_TRY_S(hipEventRecord(done[r], stream[r]));
+        }
+        for (uint32_t q = 0; q < world; ++q) {
+            HIP_TRY_S(hipSetDevice(device[q]));
+            for (uint32_t k = 1; k < world; ++k) {
+                const uint32_t r = (q + k) % world;          // every share starts with another producer: one piece per link
+                if (g[q]->recv_cnt[r] != g[r]->send_cnt[q]) { set_error("internal: shares disagree on the cited rows"); return ET_E_INVALID_ARG; }
+                HIP_TRY_S(hipStreamWaitEvent(stream[q], done[r], 0));
+                HIP_TRY_S(hipMemcpyAsync(static_cast<char*>(vec[b][q]) + (size_t)g[q]->recv_off[r] * elem,
+                                         static_cast<char*>(sendbuf[b][r]) + (size_t)g[r]->send_off[q] * elem,
+                                         (size_t)g[q]->recv_cnt[r] * elem, hipMemcpyDeviceToDevice, stream[q]));
+            }
+        }
+        // a producer packs into sendbuf[b] again two steps later; by then every puller has run the step in between, which its
+        // pulls above precede on its stream, and the producer's step after next waited for those pullers' next pieces
+        return ET_OK;
+    }
+
+    // The vector in position order on the first share's device, from the own blocks of vec[b] (the last step's output):
+    // returns the buffer et_graph_unpermute_* reads, ordered on stream[0].
+    int collect(int b, size_t elem, void** out) {
+        if (!gather) {
+            int rc = exchange_segments(b, elem);
+            *out = vec[b][0];
+            return rc;
+        }
+        const size_t seg_bytes = seg_stride * elem;
+        for (uint32_t r = 1; r < world; ++r) {
+            HIP_TRY_S(hipSetDevice(device[r]));
+            HIP_TRY_S(hipEventRecord(done[r], stream[r]));
+        }
+        HIP_TRY_S(hipSetDevice(device[0]));
+        for (uint32_t r = 0; r < world; ++r) {
+            if (r) HIP_TRY_S(hipStreamWaitEvent(stream[0], done[r], 0));
+            HIP_TRY_S(hipMemcpyAsync(static_cast<char*>(full) + r * seg_bytes, vec[b][r], seg_bytes, hipMemcpyDeviceToDevice, stream[0]));
+        }
+        *out = full;
         return ET_OK;
     }
 };
@@ -259,7 +344,9 @@ int et_sharded_create(uint32_t n, const uint8_t* member, uint64_t n_edges, const
     if (n_edges == 0 && !value_u32 && !value_fr) in.val_u32 = &dummy32;
     BuildOpts bo;
     bo.n_seg = n_devices;
-    if (n_chunks > 1 && n_devices > 1) bo.n_chunks = n_chunks;
+    // (one rank over RCCL takes the chunked exchange too: the staged all-gather, the strided copy and the phased kernels
+    // then run as several ranks would run them)
+    if (n_chunks > 1 && (n_devices > 1 || exchange == ET_EXCHANGE_RCCL)) bo.n_chunks = n_chunks;
     PlanCommon pc;
     std::string err;
     int rc = plan_common(in, bo, pc, err);
@@ -274,19 +361,22 @@ int et_sharded_create(uint32_t n, const uint8_t* member, uint64_t n_edges, const
         if ((rc = plan_segment(pc, bs, r, h, err))) { set_error(err); return rc; }
         if ((rc = DeviceGraph::create(h, s->variants, devices[r], &s->g[r]))) return rc;
     }
-    s->vec_len = s->g[0]->vec_len;
+    s->vec_len = s->g[0]->vec_len;              // position order: the same on every share; gather vectors: see g[r]->vec_len
+    s->gather = s->g[0]->geo.compact != 0;
     s->seg_stride = s->g[0]->geo.seg_stride();
     s->n_chunks = s->g[0]->geo.n_chunks;        // 1 where the graph does not take the blocked sweeps
     const size_t elem = (s->variants & ET_VARIANT_FR) ? 32 : 8;
     s->stream.assign(n_devices, nullptr);
     s->done.assign(n_devices, nullptr);
     s->pretrust.assign(n_devices, nullptr);
-    for (int b = 0; b < 2; ++b) s->vec[b].assign(n_devices, nullptr);
+    for (int b = 0; b < 2; ++b) { s->vec[b].assign(n_devices, nullptr); s->sendbuf[b].assign(n_devices, nullptr); }
     for (uint32_t r = 0; r < n_devices; ++r) {
         HIP_TRY_S(hipSetDevice(devices[r]));
         HIP_TRY_S(hipStreamCreateWithFlags(&s->stream[r], hipStreamNonBlocking));
         HIP_TRY_S(hipEventCreateWithFlags(&s->done[r], hipEventDisableTiming));
-        for (int b = 0; b < 2; ++b) HIP_TRY_S(hipMalloc(&s->vec[b][r], s->vec_len * elem));
+        for (int b = 0; b < 2; ++b) HIP_TRY_S(hipMalloc(&s->vec[b][r], s->g[r]->vec_len * elem));
+        if (s->gather)
+            for (int b = 0; b < 2; ++b) HIP_TRY_S(hipMalloc(&s->sendbuf[b][r], std::max<size_t>(1, s->g[r]->send_total) * elem));
         if (distinct)
             for (uint32_t q = 0; q < n_devices; ++q) {
                 if (q == r) continue;
@@ -315,6 +405,7 @@ int et_sharded_create(uint32_t n, const uint8_t* member, uint64_t n_edges, const
     }
     HIP_TRY_S(hipSetDevice(devices[0]));
     HIP_TRY_S(hipMalloc(&s->out_dev, (size_t)n * elem));
+    if (s->gather) HIP_TRY_S(hipMalloc(&s->full, s->g[0]->full_len * elem));
     if (exchange == ET_EXCHANGE_RCCL) {
         s->comm.assign(n_devices, nullptr);
         RCCL_TRY(rccl().CommInitAll(s->comm.data(), (int)n_devices, s->device.data()));
@@ -341,7 +432,8 @@ int et_sharded_converge_fr(et_sharded* s, uint32_t num_iterations, uint64_t init
         if ((rc = s->g[r]->init_fr(initial_lo, initial_hi, (uint4*)s->vec[0][r], s->stream[r], num_iterations == 0))) return rc;
     }
     const bool chunked = s->n_chunks > 1;
-    if ((rc = chunked ? start_chunked_exchange(s, 0, 32) : s->exchange_segments(0, 32))) return rc;
+    if (chunked) { if ((rc = start_chunked_exchange(s, 0, 32))) return rc; }
+    else if (num_iterations && (rc = s->exchange_segments(0, 32))) return rc;
     for (uint32_t it = 0; it < num_iterations; ++it) {
         const int a = it & 1, b = (it + 1) & 1;
         const uint32_t flags = it + 1 == num_iterations ? ET_STEP_FINAL : 0u;
@@ -351,12 +443,15 @@ int et_sharded_converge_fr(et_sharded* s, uint32_t num_iterations, uint64_t init
                 if (chunked) HIP_TRY_S(hipStreamWaitEvent(s->stream[r], s->ready[(size_t)r * s->n_chunks + q], 0));
                 if ((rc = s->g[r]->step_fr((const uint4*)s->vec[a][r], (uint4*)s->vec[b][r], it, flags, s->stream[r], chunked ? (int)q : -1))) return rc;
             }
-        if ((rc = chunked ? start_chunked_exchange(s, b, 32) : s->exchange_segments(b, 32))) return rc;
+        if (chunked) { if ((rc = start_chunked_exchange(s, b, 32))) return rc; }
+        else if (it + 1 < num_iterations && (rc = s->exchange_segments(b, 32))) return rc;
     }
     if (chunked)   // the result is read from the first share's vector: all of its pieces must be in
         for (uint32_t q = 0; q < s->n_chunks; ++q) { HIP_TRY_S(hipSetDevice(s->device[0])); HIP_TRY_S(hipStreamWaitEvent(s->stream[0], s->ready[q], 0)); }
+    void* result = s->vec[num_iterations & 1][0];
+    if (!chunked && (rc = s->collect(num_iterations & 1, 32, &result))) return rc;
     HIP_TRY_S(hipSetDevice(s->device[0]));
-    if ((rc = s->g[0]->unpermute_fr((const uint4*)s->vec[num_iterations & 1][0], (uint4*)s->out_dev, s->stream[0]))) return rc;
+    if ((rc = s->g[0]->unpermute_fr((const uint4*)result, (uint4*)s->out_dev, s->stream[0]))) return rc;
     HIP_TRY_S(hipMemcpyAsync(out, s->out_dev, (size_t)s->n * 32, hipMemcpyDeviceToHost, s->stream[0]));
     for (uint32_t r = 0; r < s->world; ++r) {
         HIP_TRY_S(hipSetDevice(s->device[r]));
@@ -385,16 +480,17 @@ int et_sharded_converge_f64(et_sharded* s, uint32_t num_iterations, double initi
     if (!s || !out) return ET_E_INVALID_ARG;
     if (!(s->variants & ET_VARIANT_F64)) { set_error("built without the f64 variant"); return ET_E_UNSUPPORTED; }
     int rc;
-    std::vector<double> pos;
-    if (alpha != 0.0 && pretrust) {
-        pos.resize(s->vec_len);
-        if ((rc = et_graph_permute_f64_host(reinterpret_cast<const et_graph*>(s->g[0]), pretrust, pos.data()))) return rc;
-    }
+    std::vector<std::vector<double>> pos(alpha != 0.0 && pretrust ? s->world : 0);   // a share reads its own block of its own order
     for (uint32_t r = 0; r < s->world; ++r) {
         HIP_TRY_S(hipSetDevice(s->device[r]));
         if (alpha != 0.0) {
-            if (!s->pretrust[r]) HIP_TRY_S(hipMalloc((void**)&s->pretrust[r], s->vec_len * sizeof(double)));
-            if (pretrust) HIP_TRY_S(hipMemcpyAsync(s->pretrust[r], pos.data(), s->vec_len * sizeof(double), hipMemcpyHostToDevice, s->stream[r]));
+            const size_t len = s->g[r]->vec_len;
+            if (!s->pretrust[r]) HIP_TRY_S(hipMalloc((void**)&s->pretrust[r], len * sizeof(double)));
+            if (pretrust) {
+                pos[r].resize(len);
+                if ((rc = et_graph_permute_f64_host(reinterpret_cast<const et_graph*>(s->g[r]), pretrust, pos[r].data()))) return rc;
+                HIP_TRY_S(hipMemcpyAsync(s->pretrust[r], pos[r].data(), len * sizeof(double), hipMemcpyHostToDevice, s->stream[r]));
+            }
             else if ((rc = s->g[r]->init_f64(initial, s->pretrust[r], s->stream[r], true))) return rc;   // default: the initial scores
         }
         if ((rc = s->g[r]->init_f64(initial, (double*)s->vec[0][r], s->stream[r], num_iterations == 0))) return rc;
@@ -402,7 +498,8 @@ int et_sharded_converge_f64(et_sharded* s, uint32_t num_iterations, double initi
     if (alpha != 0.0 && pretrust)   // the host staging vector must outlive the uploads
         for (uint32_t r = 0; r < s->world; ++r) { HIP_TRY_S(hipSetDevice(s->device[r])); HIP_TRY_S(hipStreamSynchronize(s->stream[r])); }
     const bool chunked = s->n_chunks > 1;
-    if ((rc = chunked ? start_chunked_exchange(s, 0, 8) : s->exchange_segments(0, 8))) return rc;
+    if (chunked) { if ((rc = start_chunked_exchange(s, 0, 8))) return rc; }
+    else if (num_iterations && (rc = s->exchange_segments(0, 8))) return rc;
     for (uint32_t it = 0; it < num_iterations; ++it) {
         const int a = it & 1, b = (it + 1) & 1;
         const uint32_t flags = it + 1 == num_iterations ? ET_STEP_FINAL : 0u;
@@ -413,12 +510,15 @@ int et_sharded_converge_f64(et_sharded* s, uint32_t num_iterations, double initi
                 if ((rc = s->g[r]->step_f64((const double*)s->vec[a][r], (double*)s->vec[b][r], it, alpha,
                                             alpha != 0.0 ? s->pretrust[r] : nullptr, flags, s->stream[r], chunked ? (int)q : -1))) return rc;
             }
-        if ((rc = chunked ? start_chunked_exchange(s, b, 8) : s->exchange_segments(b, 8))) return rc;
+        if (chunked) { if ((rc = start_chunked_exchange(s, b, 8))) return rc; }
+        else if (it + 1 < num_iterations && (rc = s->exchange_segments(b, 8))) return rc;
     }
     if (chunked)
         for (uint32_t q = 0; q < s->n_chunks; ++q) { HIP_TRY_S(hipSetDevice(s->device[0])); HIP_TRY_S(hipStreamWaitEvent(s->stream[0], s->ready[q], 0)); }
+    void* result = s->vec[num_iterations & 1][0];
+    if (!chunked && (rc = s->collect(num_iterations & 1, 8, &result))) return rc;
     HIP_TRY_S(hipSetDevice(s->device[0]));
-    if ((rc = s->g[0]->unpermute_f64((const double*)s->vec[num_iterations & 1][0], (double*)s->out_dev, s->stream[0]))) return rc;
+    if ((rc = s->g[0]->unpermute_f64((const double*)result, (double*)s->out_dev, s->stream[0]))) return rc;
     HIP_TRY_S(hipMemcpyAsync(out, s->out_dev, (size_t)s->n * sizeof(double), hipMemcpyDeviceToHost, s->stream[0]));
     for (uint32_t r = 0; r < s->world; ++r) {
         HIP_TRY_S(hipSetDevice(s->device[r]));

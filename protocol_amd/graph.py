@@ -81,21 +81,26 @@ class DistributedPlan:
             pass
 
     def local_stats(self):
-        """(row_sum uint64[n], in_degree uint32[n], out_degree uint32[n], value_max)."""
+        """(row_sum uint64[n], in_degree uint32[n], out_degree uint32[n], attested uint32[n], value_max)."""
         row_sum = np.empty(self.n, dtype=np.uint64)
         in_deg = np.empty(self.n, dtype=np.uint32)
         out_deg = np.empty(self.n, dtype=np.uint32)
+        attested = np.empty(self.n, dtype=np.uint32)
         vmax = C.c_uint32(0)
-        check(lib().et_dplan_local_stats(self._h, _ptr(row_sum), _ptr(in_deg), _ptr(out_deg), C.byref(vmax)))
-        return row_sum, in_deg, out_deg, vmax.value
+        check(lib().et_dplan_local_stats(self._h, _ptr(row_sum), _ptr(in_deg), _ptr(out_deg), _ptr(attested), C.byref(vmax)))
+        return row_sum, in_deg, out_deg, attested, vmax.value
 
-    def set_global_stats(self, row_sum, in_deg, out_deg, value_max, n_seg, seg, variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64,
-                         device=-1, n_chunks=1, long_row=0, target_work=0):
+    def set_global_stats(self, row_sum, in_deg, out_deg, attested, value_max, n_seg, seg, variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64,
+                         device=-1, n_chunks=1, long_row=0, target_work=0, full_vector=False):
         row_sum = np.ascontiguousarray(row_sum, dtype=np.uint64)
         in_deg = np.ascontiguousarray(in_deg, dtype=np.uint32)
         out_deg = np.ascontiguousarray(out_deg, dtype=np.uint32)
-        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, variants, device, n_chunks)
-        check(lib().et_dplan_set_global_stats(self._h, _ptr(row_sum), _ptr(in_deg), _ptr(out_deg), int(value_max), C.byref(opts)))
+        attested = np.ascontiguousarray(attested, dtype=np.uint32)
+        if not 0 <= int(value_max) < 2**32:
+            raise ValueError("value_max must be the largest 32-bit opinion of any process")
+        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, variants, device, n_chunks,
+                                _ffi.ET_BUILD_FULL_VECTOR if full_vector else 0)
+        check(lib().et_dplan_set_global_stats(self._h, _ptr(row_sum), _ptr(in_deg), _ptr(out_deg), _ptr(attested), int(value_max), C.byref(opts)))
         self.n_seg = n_seg
 
     def outgoing(self, share):
@@ -117,6 +122,21 @@ class DistributedPlan:
         if not (len(src) == len(row) == len(val)):
             raise ValueError("record arrays differ in length")
         check(lib().et_dplan_add_incoming(self._h, len(src), _ptr(src), _ptr(row), _ptr(val)))
+
+    def needs(self, share):
+        """The local rows of `share` this share's rows cite (ascending; empty without a gather vector and for the share
+        itself): a view into the plan's memory.  The first call ends the intake of edge records."""
+        cnt = C.c_uint64(0)
+        pr = C.c_void_p()
+        check(lib().et_dplan_needs(self._h, share, C.byref(cnt), C.byref(pr)))
+        if cnt.value == 0:
+            return np.zeros(0, dtype=np.uint32)
+        return np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_uint32)), (cnt.value,))
+
+    def add_wanted(self, share, rows):
+        """What `share` cites of this share's rows (the list its needs() returned for this share)."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        check(lib().et_dplan_add_wanted(self._h, share, len(rows), _ptr(rows)))
 
     def info(self):
         info = _ffi.EtGraphInfo()
@@ -140,7 +160,7 @@ class Graph:
 
     def __init__(self, n, frm, to, value_u32=None, value_fr=None, member=None, n_seg=1, seg=0,
                  variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64, device=-1, long_row=0,
-                 target_work=0, n_chunks=1):
+                 target_work=0, n_chunks=1, full_vector=False):
         frm = np.ascontiguousarray(frm, dtype=np.uint32)
         to = np.ascontiguousarray(to, dtype=np.uint32)
         if len(frm) != len(to):
@@ -153,7 +173,8 @@ class Graph:
             member = np.ascontiguousarray(member, dtype=np.uint8)
             if len(member) != n:
                 raise ValueError("member flags must have n entries")
-        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, variants, device, n_chunks)
+        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, variants, device, n_chunks,
+                                _ffi.ET_BUILD_FULL_VECTOR if full_vector else 0)
         h = C.c_void_p()
         check(lib().et_graph_build(n, _ptr(member), len(frm), _ptr(frm), _ptr(to), _ptr(value_u32),
                                    _ptr(value_fr), C.byref(opts), C.byref(h)))
@@ -264,7 +285,21 @@ class Graph:
         else:
             check(lib().et_graph_step_f64_phase_async(self._h, x_ptr, y_ptr, iteration, alpha, pretrust_ptr, 1 if final else 0, phase, stream))
 
+    def exchange(self):
+        """What this share sends to and receives from the others between two steps (et_exchange_info)."""
+        ex = _ffi.EtExchangeInfo()
+        check(lib().et_graph_exchange_get(self._h, C.byref(ex)))
+        return ex
+
+    def pack_fr(self, y_ptr, send_ptr, stream=None):
+        """Copies the entries of the own block of y that the other shares cite into the send buffer."""
+        check(lib().et_graph_pack_fr_async(self._h, y_ptr, send_ptr, stream))
+
+    def pack_f64(self, y_ptr, send_ptr, stream=None):
+        check(lib().et_graph_pack_f64_async(self._h, y_ptr, send_ptr, stream))
+
     def unpermute_fr(self, x_ptr, out_ptr, stream=None):
+        """x: a vector in position order (info.full_len entries)."""
         check(lib().et_graph_unpermute_fr_async(self._h, x_ptr, out_ptr, stream))
 
     def unpermute_f64(self, x_ptr, out_ptr, stream=None):
@@ -331,7 +366,7 @@ class Plan:
     Arrays are copied into numpy so they outlive the native object."""
 
     def __init__(self, n, frm, to, value_u32=None, value_fr=None, member=None, n_seg=1, seg=0,
-                 long_row=0, target_work=0):
+                 long_row=0, target_work=0, full_vector=False):
         frm = np.ascontiguousarray(frm, dtype=np.uint32)
         to = np.ascontiguousarray(to, dtype=np.uint32)
         if value_u32 is not None:
@@ -340,7 +375,7 @@ class Plan:
             value_fr = np.ascontiguousarray(value_fr, dtype=np.uint8)
         if member is not None:
             member = np.ascontiguousarray(member, dtype=np.uint8)
-        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, 0, -1, 1)
+        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, 0, -1, 1, _ffi.ET_BUILD_FULL_VECTOR if full_vector else 0)
         h = C.c_void_p()
         check(lib().et_plan_build(n, _ptr(member), len(frm), _ptr(frm), _ptr(to), _ptr(value_u32),
                                   _ptr(value_fr), C.byref(opts), C.byref(h)))
@@ -366,8 +401,19 @@ class Plan:
                 ss = _ffi.EtSweepStats()
                 check(lib().et_plan_sweep_stats(h, variant, C.byref(ss)))
                 self.sweep[name] = {f: int(getattr(ss, f)) for f, _ in _ffi.EtSweepStats._fields_}
+            # the exchange tables and, with a gather vector, the rows cited in either direction
+            ex = _ffi.EtExchangeInfo()
+            need = (C.c_void_p * 8)()
+            send = (C.c_void_p * 8)()
+            check(lib().et_plan_exchange_get(h, C.byref(ex), need, send))
+            self.exchange = ex
+            nd = int(info.nd_cap)
+            grab = lambda ptr, k: (np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), (k,)).copy()
+                                   if ptr and k else np.zeros(0, dtype=np.uint32))
+            self.need = [grab(need[c], int(ex.recv_count[c]) - nd) if ex.gather and ex.recv_count[c] else np.zeros(0, np.uint32) for c in range(8)]
+            self.send = [grab(send[c], int(ex.send_count[c]) - nd) if ex.gather and ex.send_count[c] else np.zeros(0, np.uint32) for c in range(8)]
             slots = int(info.padded_local)
-            vec_len = int(info.vec_len)
+            vec_len = int(info.full_len)
             self.pos_of_slot = np.ctypeslib.as_array(arr.pos_of_slot, (n,)).copy()
             self.slices = [(s.off, s.len, s.row0, s.nrows) for s in arr.slices[:info.n_slices]]
             self.work = [(b.slice_begin, b.slice_end, b.flags, b.dslot) for b in arr.work[:info.n_work]]

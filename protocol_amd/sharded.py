@@ -1,10 +1,15 @@
 """Row-sharded multi-GPU converge: one process per GPU, torch.distributed (RCCL) for the exchange.
 
-Every rank holds the rows (destination peers) of its segment plus a full-length trust vector.
-Per iteration a rank runs the step kernel on its rows, which writes its segment of the new vector
-and, in the segment's tail, its partial sums of the dangling-peer score mass; one in-place
-all-gather of the segments then gives every rank the whole new vector and every partial sum.
-That all-gather is the only collective on the path.
+Every rank holds the rows (destination peers) of its segment.  Per iteration a rank runs the step
+kernel on its rows, which writes its own block of the new vector: its rows' entries and, in the block's
+tail, its partial sums of the dangling-peer score mass.  One exchange per iteration then completes the
+vector on every rank, and it is the only collective on the path:
+
+  * integer opinions (the production case): a rank's vectors are gather vectors -- its own block, then
+    only the entries of the other ranks' rows that its own rows cite.  After a step the rank packs what
+    each other rank cites (et_graph_pack_*) and ONE all-to-all delivers it (RCCL: all_to_all_single);
+  * field-valued opinions, a chunked exchange, or full_vector=True: the vectors hold every rank's block
+    in position order and the exchange is one in-place all-gather of the blocks.
 
 Segments are dealt 64 rows at a time round-robin in degree order, so every rank gets the same number
 of rows and a near-identical degree mix.  The Fr variant is exact integer arithmetic: its result does
@@ -33,25 +38,27 @@ def _all_reduce_np(arr, signed_view, op, group, world, comm_device, always=False
 def distributed_plan(n, frm, to, value_u32, member=None, group=None, world=1, rank=0, comm_device=None,
                      always_collective=False, **opts):
     """The share of `rank` laid out from rank-local attestations (every attestation of an attester on one rank), ready for
-    DistributedPlan.finish() / finish_host().  Collectives: three all-reduces of per-peer figures (8 + 4 + 4 bytes per
+    DistributedPlan.finish() / finish_host().  Collectives: four all-reduces of per-peer figures (8 + 4 + 4 + 4 bytes per
     peer), one of a scalar, one all-gather of the record counts and three all-to-alls of the edge records (12 bytes per
     surviving edge in all).  `comm_device`: where tensors handed to a collective live (the GPU for RCCL, the host for
     gloo).  `always_collective`: run the collectives with a single rank too (each is then the identity): the way to
     take this function's RCCL calls on a one-GPU box."""
     comm_device = comm_device or torch.device("cpu")
     plan = DistributedPlan(n, frm, to, value_u32, member=member)
-    row_sum, in_deg, out_deg, vmax = plan.local_stats()
+    row_sum, in_deg, out_deg, attested, vmax = plan.local_stats()
     ar = lambda a, view, op: _all_reduce_np(a, view, op, group, world, comm_device, always_collective)
     row_sum = ar(row_sum, np.int64, dist.ReduceOp.SUM)
     in_deg = ar(in_deg, np.int32, dist.ReduceOp.SUM)
     out_deg = ar(out_deg, np.int32, dist.ReduceOp.SUM)
-    vmax = int(ar(np.array([vmax], dtype=np.uint32), np.int32, dist.ReduceOp.MAX)[0])
-    plan.set_global_stats(row_sum, in_deg, out_deg, vmax, world, rank, **opts)
-    del row_sum, in_deg, out_deg
+    attested = ar(attested, np.int32, dist.ReduceOp.SUM)
+    # the largest opinion as a 64-bit integer: a 32-bit opinion of 2^31 or more must not turn negative in the maximum
+    vmax = int(ar(np.array([vmax], dtype=np.int64), np.int64, dist.ReduceOp.MAX)[0])
+    plan.set_global_stats(row_sum, in_deg, out_deg, attested, vmax, world, rank, **opts)
+    del row_sum, in_deg, out_deg, attested
     outgoing = [plan.outgoing(s) for s in range(world)]
     if world == 1 and not always_collective:
         plan.add_incoming(*outgoing[0])
-        return plan
+        return plan                                          # one share: no gather vector, nobody to tell
     send = [len(o[0]) for o in outgoing]
     counts = torch.tensor(send, dtype=torch.int64, device=comm_device)
     all_counts = [torch.empty_like(counts) for _ in range(world)]
@@ -66,6 +73,24 @@ def distributed_plan(n, frm, to, value_u32, member=None, group=None, world=1, ra
         got.append(t_out.cpu().numpy().view(np.uint32))
         del buf, t_in, t_out
     plan.add_incoming(*got)
+    del got
+    if plan.info().gather:
+        # gather vectors: every rank tells the others which of their rows it cites (they pack those after every step)
+        needs = [plan.needs(s) for s in range(world)]
+        send = [len(x) for x in needs]
+        counts = torch.tensor(send, dtype=torch.int64, device=comm_device)
+        all_counts = [torch.empty_like(counts) for _ in range(world)]
+        dist.all_gather(all_counts, counts, group=group)
+        recv = [int(c[rank]) for c in all_counts]
+        t_in = torch.from_numpy(np.concatenate(needs).view(np.int32)).to(comm_device)
+        t_out = torch.empty(sum(recv), dtype=torch.int32, device=comm_device)
+        dist.all_to_all_single(t_out, t_in, recv, send, group=group)
+        wanted = t_out.cpu().numpy().view(np.uint32)
+        at = 0
+        for s in range(world):
+            if s != rank:
+                plan.add_wanted(s, wanted[at:at + recv[s]])
+            at += recv[s]
     return plan
 
 
@@ -99,8 +124,19 @@ class ShardedGraph:
         self.chunk_rows = int(info.chunk_rows)
         self.n = n
         self.vec_len = int(info.vec_len)
+        self.full_len = int(info.full_len)
         self.seg_stride = int(info.rows_cap + info.nd_cap)
-        assert self.vec_len == self.seg_stride * self.world
+        ex = self.graph.exchange()
+        self.gather = bool(ex.gather)
+        self.own_off = int(ex.own_off)
+        self.send_total = int(ex.send_total)
+        # entries sent to / received from every other rank per exchange (nothing to itself)
+        self.send_counts = [int(ex.send_count[c]) if c != self.rank else 0 for c in range(self.world)]
+        self.recv_counts = [int(ex.recv_count[c]) if c != self.rank else 0 for c in range(self.world)]
+        if self.gather:
+            assert self.own_off == 0 and self.vec_len == self.seg_stride + sum(self.recv_counts)
+        else:
+            assert self.vec_len == self.seg_stride * self.world
         self.nnz = int(info.nnz)
         self.n_valid = int(info.n_valid)
         self._vec = {}
@@ -127,7 +163,56 @@ class ShardedGraph:
         return self._vec[kind]
 
     def _segment(self, t):
-        return t[self.rank * self.seg_stride:(self.rank + 1) * self.seg_stride]
+        """This rank's own block of a vector."""
+        return t[self.own_off:self.own_off + self.seg_stride]
+
+    def exchange_bytes(self, kind):
+        """(sent, received) bytes per rank and iteration."""
+        elem = 8 if kind == "f64" else 32
+        if self.world == 1:
+            return 0, 0
+        if self.gather:
+            return self.send_total * elem, sum(self.recv_counts) * elem
+        return self.seg_stride * elem * (self.world - 1), self.seg_stride * elem * (self.world - 1)
+
+    def _exchange(self, t, kind):
+        """Completes the vector `t` whose own block this rank has just written."""
+        if not self.gather:
+            return self._all_gather(t)
+        key = ("send", kind)
+        if key not in self._vec:
+            self._vec[key] = torch.empty((max(1, self.send_total),) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
+        send = self._vec[key][:self.send_total]
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        (self.graph.pack_f64 if kind == "f64" else self.graph.pack_fr)(t.data_ptr(), send.data_ptr(), st)
+        others = t[self.seg_stride:]                      # the other ranks' blocks, in rank order
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_to_all_single(others, send, self.recv_counts, self.send_counts, group=self.group)
+        else:  # gloo (CPU rendezvous, used by tests): stage through host memory
+            host_in = send.cpu().contiguous()
+            host_out = torch.empty((sum(self.recv_counts),) + tuple(t.shape[1:]), dtype=t.dtype)
+            dist.all_to_all_single(host_out, host_in, self.recv_counts, self.send_counts, group=self.group)
+            others.copy_(host_out)
+
+    def _full_vector(self, t, kind):
+        """The vector in position order (every rank's own block) from the last step's output."""
+        if not self.gather:
+            self._all_gather(t)
+            return t
+        key = ("full", kind)
+        if key not in self._vec:
+            self._vec[key] = torch.empty((self.full_len,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
+        full = self._vec[key]
+        mine = self._segment(t)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(full, mine, group=self.group)
+        else:
+            host = mine.cpu().contiguous()
+            parts = [torch.empty_like(host) for _ in range(self.world)]
+            dist.all_gather(parts, host, group=self.group)
+            for r, p in enumerate(parts):
+                full[r * self.seg_stride:(r + 1) * self.seg_stride].copy_(p)
+        return full
 
     def _all_gather(self, t):
         """In-place all-gather of the segments of `t`."""
@@ -239,7 +324,8 @@ class ShardedGraph:
             g.init_f64(self._vec["pre"].data_ptr(), initial, st, plain=True)
             pre = self._vec["pre"].data_ptr()
         g.init_f64(x.data_ptr(), initial, st, plain=num_iterations == 0)
-        self._all_gather(x)
+        if num_iterations:
+            self._exchange(x, "f64")
         bufs = (x, y)
         for it in range(num_iterations):
             a, b = bufs[it & 1], bufs[(it + 1) & 1]
@@ -248,8 +334,9 @@ class ShardedGraph:
             g.step_f64(a.data_ptr(), b.data_ptr(), it, alpha, pre, st, final=it + 1 == num_iterations)
             if record:
                 g.record_end(st)
-            self._all_gather(b)
-        g.unpermute_f64(bufs[num_iterations & 1].data_ptr(), out.data_ptr(), st)
+            if it + 1 < num_iterations:
+                self._exchange(b, "f64")
+        g.unpermute_f64(self._full_vector(bufs[num_iterations & 1], "f64").data_ptr(), out.data_ptr(), st)
 
     def run_fr(self, num_iterations=20, initial=1000, record=False):
         st = torch.cuda.current_stream(self.device).cuda_stream
@@ -261,7 +348,8 @@ class ShardedGraph:
             return self._run_chunked("fr", num_iterations, initial, 0.0, record)
         x, y, out = self._buffers("fr")
         g.init_fr(x.data_ptr(), initial, st, plain=num_iterations == 0)
-        self._all_gather(x)
+        if num_iterations:
+            self._exchange(x, "fr")
         bufs = (x, y)
         for it in range(num_iterations):
             a, b = bufs[it & 1], bufs[(it + 1) & 1]
@@ -270,8 +358,9 @@ class ShardedGraph:
             g.step_fr(a.data_ptr(), b.data_ptr(), it, st, final=it + 1 == num_iterations)
             if record:
                 g.record_end(st)
-            self._all_gather(b)
-        g.unpermute_fr(bufs[num_iterations & 1].data_ptr(), out.data_ptr(), st)
+            if it + 1 < num_iterations:
+                self._exchange(b, "fr")
+        g.unpermute_fr(self._full_vector(bufs[num_iterations & 1], "fr").data_ptr(), out.data_ptr(), st)
 
     def result_f64(self):
         torch.cuda.synchronize(self.device)

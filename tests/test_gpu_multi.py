@@ -106,6 +106,23 @@ def test_chunked_exchange_matches_oracle(world, n, chunks):
     assert pa.fr_ints_from_bytes(mg.converge_fr(0, 1000)) == [1000 if m else 0 for m in member]
 
 
+def test_chunked_rccl_exchange_with_one_rank():
+    """The chunked exchange over RCCL -- an all-gather per piece into the staging buffer, the strided copy into place,
+    the launches waiting for their pieces -- with the one rank a single GPU allows."""
+    n = 70000
+    frm, to, val, member = _graph(n, 31)
+    iters = 6
+    rc, exp, _nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000)
+    assert rc == 0
+    rc, _e, eld, _r, _n, _s = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000.0, want_ld=True)
+    assert rc == 0
+    mg = pa.MultiGpuGraph(n, frm, to, value_u32=val, member=member, devices=[0], exchange=_ffi.ET_EXCHANGE_RCCL, n_chunks=3)
+    assert mg.exchange == _ffi.ET_EXCHANGE_RCCL and int(mg.info(0).n_chunks) == 3
+    assert np.array_equal(mg.converge_fr(iters, 1000), exp)
+    o64, _ = mg.converge_f64(iters, 1000.0)
+    assert _rel_l1(o64, eld) <= 1e-9
+
+
 def test_chunks_fall_back_where_the_sweeps_do_not_apply():
     # fewer than 16K rows per share: the exact variant runs row per lane there and the exchange stays whole
     n = 20000
@@ -146,5 +163,7 @@ def test_one_graph_stepped_in_phases():
     g.unpermute_fr(x.data_ptr(), out.data_ptr(), st)
     torch.cuda.synchronize(dev)
     assert np.array_equal(out.cpu().numpy().view(np.uint8).reshape(n, 32), exp)
-    with pytest.raises(pa.EigenTrustError):
-        g.step_fr(x.data_ptr(), y.data_ptr(), 0, st, phase=3)
+    for bad in (3, 0xFFFFFFFF):                          # a phase beyond the launches of an iteration is refused, never "all"
+        with pytest.raises(pa.EigenTrustError) as ei:
+            g.step_fr(x.data_ptr(), y.data_ptr(), 0, st, phase=bad)
+        assert ei.value.code == _ffi.ET_E_OUT_OF_RANGE

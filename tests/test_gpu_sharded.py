@@ -86,10 +86,11 @@ def test_sharded_converge_matches_oracle(world, chunks, local):
     assert ret["start"] == pa.fr_bytes_from_ints([1000 if m else 0 for m in member]).tobytes()
 
 
-@pytest.mark.parametrize("world", [4, 8])
-def test_all_shares_in_one_process(world):
+@pytest.mark.parametrize("world,full_vector", [(4, False), (8, False), (4, True)])
+def test_all_shares_in_one_process(world, full_vector):
     """The kernels on the layouts of 4 and 8 shares (what the 4- and 8-GPU runs execute), every share held by
-    this one process and the exchange done as device copies of the segments."""
+    this one process and the exchange done as device copies: the cited entries packed by the producer into the
+    consumers' gather vectors, or whole segments in position order (full_vector)."""
     import torch
     import c_oracle
     import protocol_amd as pa
@@ -106,34 +107,53 @@ def test_all_shares_in_one_process(world):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     st = torch.cuda.current_stream(dev).cuda_stream
-    graphs = [pa.Graph(n, frm, to, value_u32=val, member=member, n_seg=world, seg=r, device=0) for r in range(world)]
-    vec_len = int(graphs[0].info.vec_len)
-    stride = vec_len // world
+    graphs = [pa.Graph(n, frm, to, value_u32=val, member=member, n_seg=world, seg=r, device=0, full_vector=full_vector)
+              for r in range(world)]
+    exs = [g.exchange() for g in graphs]
+    stride = int(exs[0].own_len)
+    assert all(bool(ex.gather) == (not full_vector) for ex in exs)
     assert int(graphs[0].info.nnz) == nnz and sum(int(g.info.nnz_local) for g in graphs) == nnz
+    if not full_vector:   # a share's vectors are shorter than the vector of all peers
+        assert all(int(ex.vec_len) < int(ex.full_len) and int(ex.own_off) == 0 for ex in exs)
 
-    def exchange(vecs):
-        for r in range(world):
+    def exchange(vecs, kind):
+        for r, (g, ex) in enumerate(zip(graphs, exs)):
+            own = vecs[r][int(ex.own_off):int(ex.own_off) + stride]
+            if full_vector:
+                for q in range(world):
+                    if q != r:
+                        vecs[q][r * stride:(r + 1) * stride].copy_(own)
+                continue
+            send = torch.zeros((int(ex.send_total),) + tuple(vecs[r].shape[1:]), dtype=vecs[r].dtype, device=dev)
+            (g.pack_fr if kind == "fr" else g.pack_f64)(vecs[r].data_ptr(), send.data_ptr(), st)
             for q in range(world):
-                if q != r:
-                    vecs[q][r * stride:(r + 1) * stride].copy_(vecs[r][r * stride:(r + 1) * stride])
+                if q == r:
+                    continue
+                cnt = int(ex.send_count[q])
+                assert cnt == int(exs[q].recv_count[r])
+                vecs[q][int(exs[q].recv_off[r]):int(exs[q].recv_off[r]) + cnt].copy_(send[int(ex.send_off[q]):int(ex.send_off[q]) + cnt])
 
     for kind in ("fr", "f64"):
-        shape, dt = ((vec_len, 4), torch.int64) if kind == "fr" else ((vec_len,), torch.float64)
-        xs = [torch.zeros(shape, dtype=dt, device=dev) for _ in graphs]
-        ys = [torch.zeros(shape, dtype=dt, device=dev) for _ in graphs]
+        mk = lambda ln: torch.zeros((ln, 4), dtype=torch.int64, device=dev) if kind == "fr" else torch.zeros(ln, dtype=torch.float64, device=dev)
+        xs = [mk(int(ex.vec_len)) for ex in exs]
+        ys = [mk(int(ex.vec_len)) for ex in exs]
         for g, x in zip(graphs, xs):
             (g.init_fr if kind == "fr" else g.init_f64)(x.data_ptr(), 1000, st)
-        exchange(xs)
+        exchange(xs, kind)
         for it in range(iters):
             for g, x, y in zip(graphs, xs, ys):
                 if kind == "fr":
                     g.step_fr(x.data_ptr(), y.data_ptr(), it, st, final=it + 1 == iters)
                 else:
                     g.step_f64(x.data_ptr(), y.data_ptr(), it, 0.0, None, st, final=it + 1 == iters)
-            exchange(ys)
+            if it + 1 < iters:
+                exchange(ys, kind)
             xs, ys = ys, xs
+        # the result: every share's own block, in position order
+        full = torch.cat([x[int(ex.own_off):int(ex.own_off) + stride] for x, ex in zip(xs, exs)])
+        assert full.shape[0] == int(exs[0].full_len)
         out = torch.zeros((n, 4), dtype=torch.int64, device=dev) if kind == "fr" else torch.zeros(n, dtype=torch.float64, device=dev)
-        (graphs[0].unpermute_fr if kind == "fr" else graphs[0].unpermute_f64)(xs[0].data_ptr(), out.data_ptr(), st)
+        (graphs[0].unpermute_fr if kind == "fr" else graphs[0].unpermute_f64)(full.data_ptr(), out.data_ptr(), st)
         torch.cuda.synchronize(dev)
         if kind == "fr":
             assert out.cpu().numpy().view(np.uint8).reshape(n, 32).tobytes() == exp.tobytes()

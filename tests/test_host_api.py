@@ -163,8 +163,8 @@ def test_plan_executed_on_cpu_matches_oracle(seed):
     em = SegmentEmulator(pa.Plan(n, frm, to, value_u32=val, member=member, long_row=16, target_work=5))
     assert em.p.info.nnz == nnz
     x = em.init(1000)
-    for _ in range(4):
+    for it in range(4):
         y = [0] * len(x)
-        em.step(x, y)
+        em.step(x, y, final=it == 3)
         x = y
     assert em.unpermute(x) == c_oracle.fr_bytes_to_ints(exp)

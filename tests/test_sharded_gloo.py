@@ -9,6 +9,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -37,29 +38,55 @@ def _worker(rank, world, port, case, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    n, member, frm, to, val, iters = case
+    n, member, frm, to, val, iters, full_vector = case
     em = SegmentEmulator(pa.Plan(n, frm, to, value_u32=val, member=member, n_seg=world, seg=rank,
-                                 long_row=16, target_work=6))
-    seg = em.segment_slice()
+                                 long_row=16, target_work=6, full_vector=full_vector))
+    assert em.gather == (not full_vector)
+    own = em.own_slice()
 
-    def all_gather(x, field):
-        mine = _to_limbs(x[seg]) if field else torch.tensor(x[seg], dtype=torch.float64)
+    def as_tensor(vals, field):
+        return _to_limbs(vals) if field else torch.tensor(np.asarray(vals, dtype=np.float64))
+
+    def all_gather_own(x, field):
+        """every share's own block, in share order"""
+        mine = as_tensor(x[own], field)
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
-        for r, p in enumerate(parts):
-            vals = _from_limbs(p) if field else p.numpy()
-            x[r * em.stride:(r + 1) * em.stride] = vals
+        return [_from_limbs(p) if field else p.numpy() for p in parts]
+
+    def exchange(x, field):
+        """Completes x after init or a step, the way ShardedGraph does: an all-gather of own blocks in position order,
+        or pack + all-to-all of the cited entries into the gather vector."""
+        if not em.gather:
+            for r, vals in enumerate(all_gather_own(x, field)):
+                x[r * em.stride:(r + 1) * em.stride] = vals
+            return
+        send = [em.pack(x, c) if c != rank else [] for c in range(world)]
+        t_in = as_tensor([v for part in send for v in part], field)
+        in_splits = [len(part) for part in send]
+        out_splits = [int(em.p.exchange.recv_count[p]) if p != rank else 0 for p in range(world)]
+        assert [int(em.p.exchange.send_count[c]) if c != rank else 0 for c in range(world)] == in_splits
+        t_out = torch.empty((sum(out_splits),) + tuple(t_in.shape[1:]), dtype=t_in.dtype)
+        dist.all_to_all_single(t_out, t_in, out_splits, in_splits)
+        got = _from_limbs(t_out) if field else t_out.numpy()
+        at = 0
+        for p in range(world):
+            if p != rank:
+                x[em.recv_slice(p)] = got[at:at + out_splits[p]]
+                at += out_splits[p]
 
     out = {}
     for field in (True, False):
         x = em.init(1000 if field else 1000.0, field)
-        all_gather(x, field)
-        for _ in range(iters):
+        exchange(x, field)
+        for it in range(iters):
             y = [0] * len(x) if field else np.zeros(len(x))
-            em.step(x, y, field)
-            all_gather(y, field)
+            em.step(x, y, field, final=it + 1 == iters)
+            if it + 1 < iters:
+                exchange(y, field)
             x = y
-        out["fr" if field else "f64"] = em.unpermute(x, field)
+        full = [v for part in all_gather_own(x, field) for v in part]      # the result: own blocks in position order
+        out["fr" if field else "f64"] = em.unpermute(full, field)
     if rank == 0:
         ret["fr"] = out["fr"]
         ret["f64"] = list(out["f64"])
@@ -67,7 +94,8 @@ def _worker(rank, world, port, case, ret):
     dist.destroy_process_group()
 
 
-def test_two_rank_exchange_matches_oracle():
+@pytest.mark.parametrize("full_vector", [False, True])
+def test_two_rank_exchange_matches_oracle(full_vector):
     import c_oracle
     rng = np.random.default_rng(12)
     n = 300
@@ -87,7 +115,7 @@ def test_two_rank_exchange_matches_oracle():
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(2, port, (n, member, frm, to, val, iters), ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port + int(full_vector), (n, member, frm, to, val, iters, full_vector), ret), nprocs=2, join=True)
     assert ret["fr"] == c_oracle.fr_bytes_to_ints(exp)
     got = np.array(ret["f64"])
     assert np.abs(got - e64).sum() / np.abs(e64).sum() <= 1e-12
@@ -108,9 +136,9 @@ def _case(seed, n):
 
 def test_four_and_eight_segment_layouts_in_one_process():
     """The layouts of 4 and 8 shares (8 is the most the source encoding holds), all shares emulated in one
-    process with the exchange as a plain copy of segments."""
+    process with the exchange as plain copies: whole own blocks in position order, or the cited entries into the
+    gather vectors."""
     import c_oracle
-    import pytest
     import protocol_amd as pa
     from plan_emulator import SegmentEmulator
     n, iters = 1500, 3
@@ -119,26 +147,37 @@ def test_four_and_eight_segment_layouts_in_one_process():
     assert rc == 0
     rc, e64, _ld, _r, _n, _s = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000.0)
     assert rc == 0
-    for world in (4, 8):
-        ems = [SegmentEmulator(pa.Plan(n, frm, to, value_u32=val, member=member, n_seg=world, seg=r, long_row=16, target_work=6))
+    for world, full_vector in ((4, False), (8, False), (4, True)):
+        ems = [SegmentEmulator(pa.Plan(n, frm, to, value_u32=val, member=member, n_seg=world, seg=r, long_row=16, target_work=6,
+                                       full_vector=full_vector))
                for r in range(world)]
+        # what share c says it needs of share p is what share p says it sends to c
+        for c, ec in enumerate(ems):
+            for p, ep in enumerate(ems):
+                if c != p and not full_vector:
+                    assert np.array_equal(ec.p.need[p], ep.p.send[c])
         for field in (True, False):
             xs = [em.init(1000 if field else 1000.0, field) for em in ems]
 
             def exchange(vecs):
                 for r, em in enumerate(ems):
-                    seg = em.segment_slice()
-                    for q in range(world):
-                        if q != r:
-                            vecs[q][seg] = vecs[r][seg]
+                    for q, eq in enumerate(ems):
+                        if q == r:
+                            continue
+                        if full_vector:
+                            vecs[q][em.own_slice()] = vecs[r][em.own_slice()]
+                        else:
+                            vecs[q][eq.recv_slice(r)] = em.pack(vecs[r], q)
             exchange(xs)
-            for _ in range(iters):
-                ys = [[0] * len(xs[0]) if field else np.zeros(len(xs[0])) for _ in ems]
+            for it in range(iters):
+                ys = [[0] * len(x) if field else np.zeros(len(x)) for x in xs]
                 for em, x, y in zip(ems, xs, ys):
-                    em.step(x, y, field)
-                exchange(ys)
+                    em.step(x, y, field, final=it + 1 == iters)
+                if it + 1 < iters:
+                    exchange(ys)
                 xs = ys
-            got = ems[0].unpermute(xs[0], field)
+            full = [v for em, x in zip(ems, xs) for v in x[em.own_slice()]]
+            got = ems[0].unpermute(full, field)
             if field:
                 assert got == c_oracle.fr_bytes_to_ints(exp), world
             else:

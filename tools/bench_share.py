@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--ranks", type=int, nargs="+", default=[8])
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--chunks", type=int, default=1, help="pieces of a chunked exchange: an iteration = that many launches")
+    ap.add_argument("--full-vector", action="store_true", help="every share's whole segment in the vectors (all-gather exchange) instead of the cited entries")
     args = ap.parse_args()
 
     import torch
@@ -36,21 +37,25 @@ def main():
     st = torch.cuda.current_stream(dev).cuda_stream
     for world in args.ranks:
         t0 = time.time()
-        g = Graph(n, frm, to, value_u32=val, n_seg=world, seg=0, variants=3, device=0, n_chunks=args.chunks)
+        g = Graph(n, frm, to, value_u32=val, n_seg=world, seg=0, variants=3, device=0, n_chunks=args.chunks, full_vector=args.full_vector)
         t_build = time.time() - t0
         info = g.info
         vec_len = int(info.vec_len)
+        ex = g.exchange()
         out = {"ranks": world, "rows": int(info.n_valid) // world, "edges": int(info.nnz_local), "build_s": round(t_build, 2),
-               "chunks": int(info.n_chunks)}
+               "chunks": int(info.n_chunks), "gather_vector": bool(ex.gather), "vector_entries": vec_len, "all_peers_entries": int(ex.full_len),
+               "entries_received_per_iteration": sum(int(ex.recv_count[c]) for c in range(world)),
+               "entries_sent_per_iteration": int(ex.send_total) if ex.gather else (world - 1) * int(ex.own_len)}
         for kind_, shape, dt in (("f64", (vec_len,), torch.float64), ("fr", (vec_len, 4), torch.int64)):
             x = torch.zeros(shape, dtype=dt, device=dev)
             y = torch.zeros(shape, dtype=dt, device=dev)
             init, step = (g.init_f64, g.step_f64) if kind_ == "f64" else (g.init_fr, g.step_fr)
             init(x.data_ptr(), 1000, st)
-            # the other shares' segments: any non-zero values do, a copy of this share's
-            stride = vec_len // world
-            for r in range(1, world):
-                x[r * stride:(r + 1) * stride].copy_(x[:stride])
+            # the other shares' entries: any non-zero values do, copies of this share's
+            stride = int(info.rows_cap + info.nd_cap)
+            for off in range(stride, vec_len, stride):
+                ln = min(stride, vec_len - off)
+                x[off:off + ln].copy_(x[:ln])
             y.copy_(x)
             bufs = (x, y)
 
