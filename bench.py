@@ -55,6 +55,14 @@ def algorithmic_bytes(variant, nnz, rows):
     return nnz * 8 + rows * 100
 
 
+def own_bytes(variant, nnz, rows, value_bytes=1):
+    """Compulsory bytes of the form the kernels iterate (every array touched once, each gathered entry counted once):
+    per edge a 4-byte record (accumulator slot + source offset; one base position per 64 edges) and the opinion,
+    per row the gathered entry, its old entry, its factor, its new entry and a group entry per 16 rows."""
+    entry = 8 if variant == "f64" else 32
+    return nnz * (4 + value_bytes) + nnz // 16 + rows * 4 * entry + rows // 4
+
+
 def kernel_sources_sha():
     """Identifies the kernels a counter record was taken on: hash of the step kernels' sources and of the layout
     they run on."""
@@ -64,6 +72,30 @@ def kernel_sources_sha():
         with open(os.path.join(d, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
+
+
+def batch_sources_sha():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "protocol_amd", "csrc")
+    for name in ("batch.hip", "fr_dev.hpp"):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def batch_counter_record(kernel, sets, slots, ms_per_step):
+    """Vector-ALU counters of the small-set kernel from its PMC passes (tools/c5_counters_record.py): valid for the kernel
+    and batch shape it names, built from the sources it was taken on, while the batch time is within 10 %."""
+    path = os.path.join(ROOT, "profiles", "c5_counters.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f)
+    if rec.get("kernel") != kernel or rec.get("batch_sha") != batch_sources_sha() or (rec.get("sets"), rec.get("slots")) != (sets, slots):
+        return None
+    if abs(rec.get("ms_per_step", 0.0) - ms_per_step) > 0.10 * ms_per_step:
+        return None
+    return rec
 
 
 def counter_record(wl, kernel, launch_us):
@@ -163,6 +195,27 @@ def bench_small_sets(args, world, rank, device, red, steps, warmup, with_cpu):
         cpu = {"value": cpu_edges / len(sample), "unit": "edge-iterations/s", "cores": 1, "kind": "port",
                "sample": "3 of the %d sets, dense loop nest of the reference restated in C, one thread" % sets}
     ops = sets * NUM_ITER * steps * 2.0 * 32 * slots * slots / elapsed / 1e12
+    kernel = "k_batch_fr_mfma_packed" if slots <= 32 else ("k_batch_fr_mfma" if slots <= 256 else "k_batch_fr_mfma_stream")
+    # What bounds the kernel is the per-element field arithmetic on the vector ALUs: the roofline is the issue rate of
+    # vector instructions, 1024 SIMDs x one wave-instruction per 4 cycles at 2.4 GHz (an MFMA holds a SIMD's issue for 8).
+    # The instruction counts come from the PMC passes of this same batch shape; the launch time is measured here.
+    rec = batch_counter_record(kernel, sets, slots, elapsed / steps * 1e3) if world == 1 else None
+    valu_peak = 1024 * 2.4e9 / 4 / 1e9                       # G wave-instructions / s
+    if rec:
+        mfma = rec.get("SQ_INSTS_MFMA", 0.0)
+        slots_used = (rec["SQ_INSTS_VALU"] - mfma) + 2.0 * mfma           # in 4-cycle issue slots
+        valu_rate = slots_used / (elapsed / steps) / 1e9
+        roof = {"bound": "valu", "achieved": valu_rate, "peak": valu_peak, "unit": "G wave-instructions/s (4-cycle issue slots)",
+                "frac": valu_rate / valu_peak, "traffic": None, "kernel": kernel,
+                "valu_instructions_per_launch": rec["SQ_INSTS_VALU"], "mfma_instructions_per_launch": mfma,
+                # the same against the cycles the counters saw (the clock under this load is below 2.4 GHz)
+                "frac_of_measured_cycles": slots_used * 4.0 / (1024 * rec["GRBM_GUI_ACTIVE"] / 8.0) if rec.get("GRBM_GUI_ACTIVE") else None,
+                "mfma_i8_TOPs": ops, "mfma_frac_of_i8_peak": ops / 5000.0,
+                "note": "bound by 32-bit vector-ALU field arithmetic; the byte-limb product runs on the matrix cores beside it"}
+    else:
+        roof = {"bound": "valu", "achieved": None, "peak": valu_peak, "unit": "G wave-instructions/s (4-cycle issue slots)", "frac": None,
+                "traffic": None, "kernel": kernel, "mfma_i8_TOPs": ops, "mfma_frac_of_i8_peak": ops / 5000.0,
+                "note": "no counter record for this kernel, batch shape and build (profiles/c5_counters.json)"}
     return {
         "metric": "edge-iterations/sec", "value": edges * NUM_ITER * steps / elapsed, "unit": "edge-iterations/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
@@ -171,13 +224,7 @@ def bench_small_sets(args, world, rank, device, red, steps, warmup, with_cpu):
                    "sets": sets, "slots": slots, "iterations": NUM_ITER, "parallelism": "sets split x%d" % world,
                    "seed": args.seed},
         "sets_per_s": sets * steps / elapsed,
-        # the dense product runs as byte-limb i8 MFMA tiles (32 limbs x 256 sources x 256 columns per set and
-        # iteration, plus a third as many against a matrix of ones); i8 dense peak = 2 x bf16.  The launch is
-        # bound by the per-element field arithmetic on the vector ALUs, not by the matrix cores.
-        "roofline": {"bound": "mfma", "achieved": ops, "peak": 5000.0, "unit": "TFLOP/s", "frac": ops / 5000.0,
-                     "traffic": None,
-                     "kernel": "k_batch_fr_mfma_packed" if slots <= 32 else ("k_batch_fr_mfma" if slots <= 256 else "k_batch_fr_mfma_stream"),
-                     "note": "integer ops of the byte-limb product; the kernel's bound is 32-bit VALU field arithmetic"},
+        "roofline": roof,
         "cpu_baseline": cpu,
         "checks": {"all_status_ok": ok, "sampled_sets_bit_exact": ok},
         "setup_s": {"create": t_create},
@@ -219,7 +266,10 @@ def bench_set_latency(args):
             "cpu_baseline": {"kind": "port", "cores": 1, "sample": "dense loop nest of native.rs:286-337 restated in C, one call"}}
 
 
-def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu):
+def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu, value_max=255, alpha=0.0, variant=None):
+    """value_max: opinions are drawn uniformly from 1..value_max (255: the reference's u8 attestation value,
+    eigentrust/src/attestation.rs:304; 2^32 - 1: the stress set for opinions that do not fit a byte).
+    alpha: damping of the f64 variant with the initial scores as pre-trust (0: the reference's update)."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -229,15 +279,16 @@ def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu):
 
     kind, n, target_edges, desc = WORKLOADS[wl]
     t0 = time.time()
+    variant = variant or args.variant
     if world == 1:
-        frm, to, val = pa.synth_graph(kind, n, target_edges, seed=args.seed, value_max=255)
+        frm, to, val = pa.synth_graph(kind, n, target_edges, seed=args.seed, value_max=value_max)
     else:
         # every rank ingests the attestations of its own range of attesters only; the ranks agree on the layout and
         # send each edge to the rank that owns its destination row (no rank holds the whole list)
         frm, to, val = pa.synth_graph_range(kind, n, target_edges, n * rank // world, n * (rank + 1) // world,
-                                            seed=args.seed, value_max=255)
+                                            seed=args.seed, value_max=value_max)
     t_gen = time.time() - t0
-    variants = {"both": 3, "fr": 1, "f64": 2}[args.variant]
+    variants = {"both": 3, "fr": 1, "f64": 2}[variant]
     t0 = time.time()
     sg = ShardedGraph(n, frm, to, value_u32=val, device=device, variants=variants, n_chunks=args.chunks,
                       local_attestations=world > 1)
@@ -270,10 +321,11 @@ def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu):
 
     fr_kernel = sg.graph.exact_kernel_name()
     results = {}
-    for variant in (["f64", "fr"] if args.variant == "both" else [args.variant]):
+    value_bytes = 1 if value_max <= 255 else 4
+    for variant in (["f64", "fr"] if variant == "both" else [variant]):
         if variant == "f64":
             def run(rec):
-                return sg.run_f64(NUM_ITER, float(INITIAL), 0.0, record=rec)
+                return sg.run_f64(NUM_ITER, float(INITIAL), alpha, record=rec)
         else:
             def run(rec):
                 return sg.run_fr(NUM_ITER, INITIAL, record=rec)
@@ -299,8 +351,10 @@ def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu):
         rows_local = int(info.n_valid) // world
         alg = algorithmic_bytes(variant, int(info.nnz_local), rows_local)
         achieved = alg / launch_s / 1e9
-        kernel = "k_step_f64_blocked<u8>" if variant == "f64" else fr_kernel
-        rec = counter_record(wl, kernel, launch_s * 1e6) if world == 1 else None
+        kernel = ("k_step_f64_blocked<u8>" if value_bytes == 1 else "k_step_f64_blocked<u32>") if variant == "f64" else fr_kernel
+        rec = counter_record(wl, kernel, launch_s * 1e6) if world == 1 and value_max == 255 and alpha == 0.0 else None
+        own = own_bytes(variant, int(info.nnz_local), rows_local, value_bytes)
+        sent, received = sg.exchange_bytes(variant)
         per_iteration_us = elapsed / steps / NUM_ITER * 1e6
         results[variant] = {
             "value": nnz * NUM_ITER * steps / elapsed,
@@ -309,9 +363,19 @@ def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu):
             # rank), from the wall time of a step and the event time of rank 0's launches
             "iteration_us": {"total": per_iteration_us, "launches": launch_s * 1e6,
                              "exchange_and_waits": max(0.0, per_iteration_us - launch_s * 1e6)} if world > 1 else None,
+            # N > 1: what one rank sends and receives between two iterations (a gather vector holds only the entries the
+            # rank's rows cite; the all-gather of whole segments would receive the last figure)
+            "exchange": {"gather_vector": bool(sg.gather), "bytes_sent_per_rank": sent, "bytes_received_per_rank": received,
+                         "vector_entries": sg.vec_len, "all_peers_entries": sg.full_len,
+                         "all_gather_bytes_received_per_rank": sg.seg_stride * (8 if variant == "f64" else 32) * (world - 1)} if world > 1 else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": rec["traffic_bytes"] if rec else None,
+                         # the same launch priced two more ways: by the bytes the counters saw cross the fabric, and by the
+                         # compulsory bytes of the form the kernel iterates (smaller records than the CSR figure above)
+                         "frac_traffic": rec["traffic_bytes"] / launch_s / 1e9 / HBM_PEAK_GBS if rec else None,
+                         "own_bytes_per_launch": own,
+                         "frac_own_bytes": own / launch_s / 1e9 / HBM_PEAK_GBS,
                          "kernel": kernel,
                          "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": alg,
                          "device_copy_GBs": copy_gbs},
@@ -323,6 +387,12 @@ def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu):
             # longer, so this is a lower bound) over 1024 SIMDs x the cycles of the launch
             r["valu_issue_frac"] = (rec["SQ_INSTS_VALU"] * 4.0 / (1024 * rec["GRBM_GUI_ACTIVE"] / 8.0)
                                     if rec and "SQ_INSTS_VALU" in rec and "GRBM_GUI_ACTIVE" in rec else None)
+            # the same with the measured issue cost of the kernel's instruction mix: 5.7 cycles for a 64-bit multiply-add
+            # (tools/microbench/mad_vs_fma64.hip), 4 for the others; the multiply-adds are counted from the kernel's code
+            # (8 per edge in the sweep, 145 per row)
+            if r["valu_issue_frac"] is not None:
+                mads = (8.0 * int(info.nnz_local) + 145.0 * rows_local) / 64.0
+                r["valu_issue_frac_weighted"] = ((rec["SQ_INSTS_VALU"] - mads) * 4.0 + mads * 5.7) / (1024 * rec["GRBM_GUI_ACTIVE"] / 8.0)
             r["form"] = "factored (raw opinions, pre-scaled vector)"
             r["weighted_csr_bytes_per_launch"] = int(info.nnz_local) * 36 + rows_local * 68
 
@@ -381,7 +451,8 @@ def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu):
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
         "dtype": "f64" if "f64" in results else "fr254", "data": "synthetic",
-        "config": {"workload": "%s: %s; %d iterations per step; byte opinions kept raw in the edge records" % (wl, desc, NUM_ITER),
+        "config": {"workload": "%s: %s; %d iterations per step; opinions 1..%d kept raw in the edge records%s" % (
+                       wl, desc, NUM_ITER, value_max, "; damping alpha = %g, pre-trust = the initial scores" % alpha if alpha else ""),
                    "peers": n, "edges": nnz, "iterations": NUM_ITER, "parallelism": "rows sharded x%d" % world,
                    "exchange_pieces": sg.n_chunks, "seed": args.seed},
         "roofline": head["roofline"],
@@ -391,6 +462,7 @@ def bench_graph(args, wl, world, rank, device, red, steps, warmup, with_cpu):
     }
     if world > 1:
         line["iteration_us"] = head["iteration_us"]
+        line["exchange"] = head["exchange"]
     if "fr" in results and "f64" in results:
         line["fr_exact"] = dict(results["fr"], dtype="fr254 (8x32-bit limbs)", unit="edge-iterations/s")
     sg.graph.close()
@@ -459,11 +531,17 @@ def main():
             c2 = bench_graph(args, "c2", 1, 0, device, red, max(3, args.steps // 2), 2, with_cpu)
             args.variant = saved
             c5 = bench_small_sets(args, 1, 0, device, red, max(3, args.steps // 2), 2, with_cpu)
-            keep = ("value", "unit", "ms_per_step", "roofline", "fr_exact", "cpu_baseline", "checks", "sets_per_s", "dtype")
+            few = max(3, args.steps // 2)
+            # opinions that do not fit a byte (the reference's opinion is any field element, native.rs:128), the damped f64
+            # update, and the 16M-peer graph on ONE GPU (the N = 1 point of the multi-GPU curve; no CPU leg: it takes minutes)
+            u32 = bench_graph(args, "c3", 1, 0, device, red, few, 2, False, value_max=0xFFFFFFFF)
+            damped = bench_graph(args, "c3", 1, 0, device, red, few, 2, False, alpha=0.15, variant="f64")
+            big = bench_graph(args, "c4", 1, 0, device, red, 2, 1, False)
+            keep = ("value", "unit", "ms_per_step", "roofline", "fr_exact", "cpu_baseline", "checks", "sets_per_s", "dtype", "setup_s")
+            pick = lambda r: dict({k: r[k] for k in keep if k in r}, workload=r["config"]["workload"])
             line["configs"] = {
-                "c2": dict({k: c2[k] for k in keep if k in c2}, workload=c2["config"]["workload"]),
-                "c5": dict({k: c5[k] for k in keep if k in c5}, workload=c5["config"]["workload"]),
-                "c1": bench_set_latency(args),
+                "c2": pick(c2), "c5": pick(c5), "c1": bench_set_latency(args),
+                "c3_u32": pick(u32), "c3_alpha015": pick(damped), "c4_one_gpu": pick(big),
             }
     if rank == 0:
         print(json.dumps(line), flush=True)

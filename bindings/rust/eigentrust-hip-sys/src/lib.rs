@@ -84,6 +84,7 @@ pub struct et_build_opts {
     pub device: i32,
     pub n_chunks: u32,
     pub flags: u32,
+    pub xcd_cost: [u32; 8],
 }
 pub const ET_BUILD_FULL_VECTOR: u32 = 1;
 
@@ -110,6 +111,7 @@ pub struct et_graph_info {
     pub chunk_rows: u32,
     pub gather: u32,
     pub full_len: u64,
+    pub xcd_cost: [u32; 8],
 }
 
 /// What a share sends to and receives from the others between two steps (entries, not bytes).
@@ -175,6 +177,7 @@ pub struct et_sweep_stats {
     pub edges_most: u64,
     pub line_fills: u64,
     pub line_fills_most: u64,
+    pub chunk_span_most: u64,
 }
 
 #[repr(C)]

@@ -139,6 +139,11 @@ typedef struct {
                                piece q + 1 can run beside the launch over piece q.  Honoured where both
                                variants run the blocked sweep (see et_graph_info.n_chunks)               */
     uint32_t flags;         /* ET_BUILD_* bit mask                                                    */
+    uint32_t xcd_cost[8];   /* relative time per edge of a workgroup on XCD 0..7, in 1/1024 (workgroup b of a
+                               sweep runs on XCD b mod 8): the deal levels edges x cost.  All zero = measured on
+                               the device by a short probe (et_graph_build, et_dplan_finish, et_sharded_create) or
+                               uniform (et_plan_build).  et_graph_info.xcd_cost reports what a layout was levelled
+                               with; passing those values back reproduces the layout                          */
 } et_build_opts;
 /* Several shares: keep every share's whole segment in the trust vectors (position order, all-gather exchange) even
  * where the gather vector (see et_exchange_info) would be used. */
@@ -166,6 +171,7 @@ typedef struct {
     uint32_t gather;        /* 1: the share's vectors are gather vectors (see et_exchange_info)          */
     uint64_t full_len;      /* n_seg * (rows_cap + nd_cap): entries of a vector in position order, which is
                                what et_graph_unpermute_* reads                                            */
+    uint32_t xcd_cost[8];   /* the per-XCD cost factors the layout was levelled with (see et_build_opts)  */
 } et_graph_info;
 
 /* Filter + normalise + lay out an attestation list (see et_set_update_op for the meaning of a
@@ -212,6 +218,7 @@ typedef struct {
     uint32_t clustered;
     uint64_t edges, edges_most;            /* all workgroups, the busiest one */
     uint64_t line_fills, line_fills_most;
+    uint64_t chunk_span_most;              /* widest range of positions 64 consecutive edges of a list span */
 } et_sweep_stats;
 int et_plan_sweep_stats(const et_plan *p, int variant, et_sweep_stats *out);
 /* Uploads a plan (what et_graph_build does after planning). */

@@ -45,7 +45,7 @@ class EtFr(C.Structure):
 class EtBuildOpts(C.Structure):
     _fields_ = [("n_seg", C.c_uint32), ("seg", C.c_uint32), ("long_row", C.c_uint32),
                 ("target_work", C.c_uint32), ("variants", C.c_uint32), ("device", C.c_int32),
-                ("n_chunks", C.c_uint32), ("flags", C.c_uint32)]
+                ("n_chunks", C.c_uint32), ("flags", C.c_uint32), ("xcd_cost", C.c_uint32 * 8)]
 
 
 ET_BUILD_FULL_VECTOR = 1
@@ -60,7 +60,7 @@ class EtGraphInfo(C.Structure):
                 ("vec_len", C.c_uint64), ("device_bytes", C.c_uint64),
                 ("f64_sweep_blocks", C.c_uint32), ("exact_sweep_blocks", C.c_uint32),
                 ("n_chunks", C.c_uint32), ("chunk_rows", C.c_uint32),
-                ("gather", C.c_uint32), ("full_len", C.c_uint64)]
+                ("gather", C.c_uint32), ("full_len", C.c_uint64), ("xcd_cost", C.c_uint32 * 8)]
 
 
 class EtExchangeInfo(C.Structure):
@@ -91,7 +91,7 @@ class EtPlanArrays(C.Structure):
 
 class EtSweepStats(C.Structure):
     _fields_ = [("blocks", C.c_uint32), ("clustered", C.c_uint32), ("edges", C.c_uint64), ("edges_most", C.c_uint64),
-                ("line_fills", C.c_uint64), ("line_fills_most", C.c_uint64)]
+                ("line_fills", C.c_uint64), ("line_fills_most", C.c_uint64), ("chunk_span_most", C.c_uint64)]
 
 
 class EtScore(C.Structure):

@@ -559,6 +559,45 @@ namespace {
 // order of the source's visit key (position; piece by piece with a chunked exchange) in T contiguous chunks of the order.
 // visit(local row, source code (segment << 29 | local row), handle); the handle fetches the edge's value.
 
+// Gather vectors: the order a share asks for the entries of another share's rows.
+//
+// A blocked sweep is bound by the 128-byte lines a workgroup's gathers pull into its L1, and a source cited a few times
+// costs one line per edge when its line-mates are gathered by other workgroups.  The entries of ANOTHER share's rows
+// have no place of their own in this share's vector, so the share puts them where its workgroups want them: the
+// sources its rows cite `hot` times or more keep the front of their block, in position order (most-attesting first:
+// nearly every workgroup gathers them anyway), and the others follow grouped by the workgroup that cites them most,
+// then by the workgroup that cites them next, so that a line of sixteen (four) entries serves one workgroup sixteen
+// (four) times.  `src` lists one block's cited sources: local row, citing edges, the two workgroups citing most.
+struct CitedSource { uint32_t local, edges, wg1, wg2; };
+static void order_cited_sources(std::vector<CitedSource>& src, uint32_t hot, uint32_t fold) {
+    // workgroups b and b + fold of the sweep with more workgroups are ONE workgroup of the other sweep: side by side
+    auto wg_key = [&](uint32_t w) -> uint64_t { return w == 0xFFFFFFFFu ? 0xFFFFFFFFull : (uint64_t)(w % fold) * 64 + w / fold; };
+    std::sort(src.begin(), src.end(), [&](const CitedSource& a, const CitedSource& b) {
+        const bool ha = a.edges >= hot, hb = b.edges >= hot;
+        if (ha != hb) return ha;
+        if (ha) return a.local < b.local;
+        const uint64_t ka = wg_key(a.wg1), kb = wg_key(b.wg1);
+        if (ka != kb) return ka < kb;
+        const uint64_t sa = wg_key(a.wg2), sb = wg_key(b.wg2);
+        if (sa != sb) return sa < sb;
+        return a.local < b.local;
+    });
+}
+// the two workgroups with the most votes (ties: the smaller hash of (source, workgroup), so that no workgroup is favoured)
+struct VoteBox {
+    std::vector<uint32_t> votes, touched;
+    explicit VoteBox(uint32_t B) : votes(B, 0) {}
+    void add(uint32_t w) { if (votes[w]++ == 0) touched.push_back(w); }
+    void take(uint32_t who, uint32_t& w1, uint32_t& w2) {
+        auto mix = [&](uint32_t l) { uint64_t z = ((uint64_t)who << 20 ^ l) * 0x9E3779B97F4A7C15ull; return z ^ (z >> 29); };
+        w1 = w2 = 0xFFFFFFFFu;
+        for (uint32_t l : touched) if (w1 == 0xFFFFFFFFu || votes[l] > votes[w1] || (votes[l] == votes[w1] && mix(l) < mix(w1))) w1 = l;
+        for (uint32_t l : touched) if (l != w1 && (w2 == 0xFFFFFFFFu || votes[l] > votes[w2] || (votes[l] == votes[w2] && mix(l) < mix(w2)))) w2 = l;
+        for (uint32_t l : touched) votes[l] = 0;
+        touched.clear();
+    }
+};
+
 // ... from the attestation list itself (one process holds all of it): attesters are walked in visit order.
 struct AttesterWalk {
     const PlanCommon& pc;
@@ -634,6 +673,11 @@ struct AttesterWalk {
             }
             by_pos.assign(pc.order.begin(), pc.order.begin() + n_active);
         }
+        sort_walk();
+    }
+    void sort_walk() {
+        const Geometry& geo = g.geo;
+        const uint32_t stride = geo.seg_stride();
         auto visit_key = [&](uint32_t ext) -> uint64_t {
             if (geo.compact) return code_of_ext[ext];
             const uint32_t p = g.pos_of_ext[ext];
@@ -649,6 +693,47 @@ struct AttesterWalk {
             chunk_cut[t] = (uint32_t)(std::lower_bound(pos_edges.begin(), pos_edges.end(), pos_edges[n_walk] * t / T) - pos_edges.begin());
         for (unsigned t = 1; t <= T; ++t) chunk_cut[t] = std::min<uint32_t>(n_walk, std::max(chunk_cut[t], chunk_cut[t - 1]));
         chunk_cut[T] = n_walk;
+    }
+    // Gather vectors: the other shares' entries in the order this share's workgroups want them (order_cited_sources);
+    // wg_of_group = the workgroup that sums each 16-row group.  The shares that pack for this one must be told (g.need).
+    void cluster_cited(HostGraph&, const std::vector<uint32_t>& wg_of_group, uint32_t n_wg, uint32_t hot, uint32_t fold) {
+        const Geometry& geo = g.geo;
+        const uint32_t stride = geo.seg_stride(), n_walk = (uint32_t)by_pos.size();
+        std::vector<CitedSource> cs(n_walk);
+        run_threads(T, [&](unsigned t) {
+            VoteBox box(n_wg);
+            for (uint32_t i = (uint32_t)((uint64_t)n_walk * t / T); i < (uint32_t)((uint64_t)n_walk * (t + 1) / T); ++i) {
+                const uint32_t f = by_pos[i];
+                uint32_t edges = 0;
+                for (uint64_t k = pc.out_ptr[f]; k < pc.out_ptr[f + 1]; ++k)
+                    if (lr_of_edge[k] != 0xFFFFFFFFu) { box.add(wg_of_group[lr_of_edge[k] / BLOCK_GROUP]); ++edges; }
+                cs[i].local = g.pos_of_ext[f] % stride;
+                cs[i].edges = edges;
+                box.take(f, cs[i].wg1, cs[i].wg2);
+            }
+        });
+        std::vector<std::vector<CitedSource>> per(geo.n_seg);
+        for (uint32_t i = 0; i < n_walk; ++i) {
+            const uint32_t p = g.pos_of_ext[by_pos[i]] / stride;
+            if (p != geo.seg) per[p].push_back(cs[i]);
+        }
+        std::vector<uint32_t> ext_of_local;
+        for (uint32_t p = 0; p < geo.n_seg; ++p) {
+            if (p == geo.seg) continue;
+            ext_of_local.assign(stride, 0xFFFFFFFFu);
+            for (uint32_t i = 0; i < n_walk; ++i) {
+                const uint32_t pos = g.pos_of_ext[by_pos[i]];
+                if (pos / stride == p) ext_of_local[pos % stride] = by_pos[i];
+            }
+            order_cited_sources(per[p], hot, fold);
+            g.need[p].resize(per[p].size());
+            for (uint32_t j = 0; j < per[p].size(); ++j) {
+                g.need[p][j] = per[p][j].local;
+                code_of_ext[ext_of_local[per[p][j].local]] = g.blk_off[p] + j;
+            }
+        }
+        g.send_known = false;        // the lists derived above assumed every share asks in ascending order: no longer true of the others
+        sort_walk();
     }
     void count_rows(std::vector<uint64_t>& in_ptr) const {
         const uint32_t n = pc.in.n;
@@ -770,6 +855,67 @@ struct RecordWalk {
             }
         });
     }
+    // see AttesterWalk::cluster_cited
+    void cluster_cited(HostGraph& g, const std::vector<uint32_t>& wg_of_group, uint32_t n_wg, uint32_t hot, uint32_t fold) {
+        const uint32_t stride = geo.seg_stride();
+        std::vector<std::vector<CitedSource>> per(geo.n_seg);
+        std::vector<std::vector<uint32_t>> old_code(geo.n_seg);
+        {
+            VoteBox box(n_wg);
+            uint64_t k = 0;
+            while (k < count) {
+                const uint32_t code = src[k];
+                uint32_t edges = 0;
+                for (; k < count && src[k] == code; ++k) { box.add(wg_of_group[row[k] / BLOCK_GROUP]); ++edges; }
+                CitedSource c{0, edges, 0, 0};
+                box.take(code, c.wg1, c.wg2);
+                if (code < stride) continue;                                    // the share's own block keeps its order
+                uint32_t p = 0;
+                for (uint32_t q = 0; q < geo.n_seg; ++q) if (q != geo.seg && code >= g.blk_off[q]) p = q;   // blocks ascend with the share
+                c.local = g.need[p][code - g.blk_off[p]];
+                per[p].push_back(c);
+            }
+        }
+        std::vector<uint32_t> remap(geo.vec_len);
+        for (uint32_t i = 0; i < geo.vec_len; ++i) remap[i] = i;
+        std::vector<uint32_t> code_of_local;
+        for (uint32_t p = 0; p < geo.n_seg; ++p) {
+            if (p == geo.seg) continue;
+            code_of_local.assign(stride, 0xFFFFFFFFu);
+            for (uint32_t j = 0; j < g.need[p].size(); ++j) code_of_local[g.need[p][j]] = g.blk_off[p] + j;
+            order_cited_sources(per[p], hot, fold);
+            for (uint32_t j = 0; j < per[p].size(); ++j) {
+                remap[code_of_local[per[p][j].local]] = g.blk_off[p] + j;
+                g.need[p][j] = per[p][j].local;
+            }
+        }
+        // the records again in ascending order of their (new) source index
+        struct Rec { uint32_t src, row, val; };
+        std::vector<uint64_t> cnt((size_t)T * T, 0);
+        auto bucket_of = [&](uint32_t c) -> unsigned { return (unsigned)std::min<uint64_t>(T - 1, (uint64_t)c * T / geo.vec_len); };
+        run_threads(T, [&](unsigned t) {
+            for (uint64_t k = count * t / T; k < count * (t + 1) / T; ++k) { src[k] = remap[src[k]]; ++cnt[(size_t)t * T + bucket_of(src[k])]; }
+        });
+        std::vector<uint64_t> begin(T + 1, 0);
+        {
+            uint64_t run = 0;
+            for (unsigned d = 0; d < T; ++d) {
+                begin[d] = run;
+                for (unsigned t = 0; t < T; ++t) { const uint64_t c = cnt[(size_t)t * T + d]; cnt[(size_t)t * T + d] = run; run += c; }
+            }
+            begin[T] = run;
+        }
+        std::vector<Rec> buf(count);
+        run_threads(T, [&](unsigned t) {
+            for (uint64_t k = count * t / T; k < count * (t + 1) / T; ++k) buf[cnt[(size_t)t * T + bucket_of(src[k])]++] = Rec{src[k], row[k], val[k]};
+        });
+        run_threads(T, [&](unsigned d) {
+            std::sort(buf.begin() + begin[d], buf.begin() + begin[d + 1], [](const Rec& a, const Rec& b) { return a.src != b.src ? a.src < b.src : a.row < b.row; });
+        });
+        run_threads(T, [&](unsigned t) {
+            for (uint64_t k = count * t / T; k < count * (t + 1) / T; ++k) { src[k] = buf[k].src; row[k] = buf[k].row; val[k] = buf[k].val; }
+        });
+    }
     void count_rows(std::vector<uint64_t>& in_ptr) const {
         run_threads(T, [&](unsigned t) {
             for (uint64_t k = count * t / T; k < count * (t + 1) / T; ++k) __atomic_fetch_add(&in_ptr[row[k] + 1], 1, __ATOMIC_RELAXED);
@@ -784,23 +930,29 @@ struct RecordWalk {
 };
 
 // Steps 7-10: one share's edge lists.  `g` holds the common part (geometry with geo.seg set, positions, factors).
+// In two parts: deal_segment counts the rows' in-edges, hands the row groups to the sweeps' workgroups and -- gather
+// vectors with cluster_cited -- settles the order of the other shares' entries (g.need; the shares that pack for this one
+// are told between the two parts); fill_segment writes the edge lists.
+struct Deal { std::vector<uint32_t> block, slot; };
+struct DealtSegment {
+    std::vector<uint64_t> in_ptr;
+    Deal d64, dfr;
+};
+
 template <class Src>
-int lay_out_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned T, std::string& err) {
+int deal_segment(HostGraph& g, const BuildOpts& opt, Src& src, DealtSegment& ds) {
     const Geometry geo = g.geo;
-    const uint32_t seg_index = geo.seg;
-    const uint32_t G = geo.n_seg, n_active = geo.n_active, n_dangling = geo.n_dangling;
-    const uint32_t target_work = opt.target_work ? opt.target_work : 16384;
+    for (int x = 0; x < 8; ++x) g.xcd_cost[x] = opt.xcd_cost[x];
+    const uint32_t G = geo.n_seg;
+    std::vector<uint64_t>& in_ptr = ds.in_ptr;
     // ---- 7. in-edges of this segment's rows, sources ascending by position -------------------
     // The passes below scatter every surviving edge by destination row; they run on several host
     // threads, each owning a contiguous range of rows (or of workgroups), so that no two threads
     // write the same counter and every thread emits its edges in the same, source-ascending order.
-    std::vector<uint64_t> in_ptr((size_t)geo.rows_cap + 1, 0);
+    in_ptr.assign((size_t)geo.rows_cap + 1, 0);
     src.count_rows(in_ptr);
     for (uint32_t i = 0; i < geo.rows_cap; ++i) in_ptr[i + 1] += in_ptr[i];
     g.nnz_local = in_ptr[geo.rows_cap];
-    const bool per_row_stream = geo.fr_blocks == 0;      // else the exact variant runs the blocked sweep too
-    std::vector<uint32_t> e_src(per_row_stream ? g.nnz_local : 0);   // source, encoded (segment << 29) | local row
-    std::vector<uint64_t> e_idx(per_row_stream ? g.nnz_local : 0);   // the edge's value handle
     // The same edges grouped by workgroup of the f64 blocked sweep, ascending by source.  The row
     // groups are handed out heaviest first, each to the workgroup with the fewest edges so far that
     // still has a free accumulator slot: a launch ends with its slowest workgroup, so edge counts
@@ -808,7 +960,6 @@ int lay_out_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned
     const uint32_t n_groups = geo.rows_cap / BLOCK_GROUP, first_dangling_group = geo.n_active_pad / BLOCK_GROUP / G;
     std::vector<uint64_t> grp_edges(n_groups);
     for (uint32_t gi = 0; gi < n_groups; ++gi) grp_edges[gi] = in_ptr[(size_t)(gi + 1) * BLOCK_GROUP] - in_ptr[(size_t)gi * BLOCK_GROUP];
-    struct Deal { std::vector<uint32_t> block, slot; };
     auto deal = [&](uint32_t B, uint32_t gpb, uint32_t dblocks, std::vector<uint32_t>& grp_table, std::vector<uint64_t>& ptr) {
         Deal d;
         d.block.assign(n_groups, 0);
@@ -849,11 +1000,42 @@ int lay_out_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned
             }
         };
         pass(first_dangling_group, n_groups, dblocks, false);
-        pass(0, first_dangling_group, B, g.hint_blocks != 0 && g.hint_blocks % B == 0 && G == 1);
+        pass(0, first_dangling_group, B, g.hint_blocks != 0 && g.hint_blocks % B == 0);
         for (uint32_t bb = 0; bb < B; ++bb) ptr[bb + 1] = ptr[bb] + edges[bb];
         return d;
     };
-    const Deal d64 = deal(geo.f64_blocks, geo.f64_rb / BLOCK_GROUP, geo.f64_dblocks, g.bk_grp, g.bk_ptr);
+    // The exact sweep's deal first.  Gather vectors whose entries are ordered by citing workgroup (cluster_cited): the f64
+    // sweep's workgroup b then takes the row groups of the exact sweep's workgroups b, b + f64_blocks, ..., so that both
+    // sweeps find a workgroup's sources side by side.
+    Deal& dfr = ds.dfr;
+    if (geo.fr_blocks) dfr = deal(geo.fr_blocks, geo.fr_rb / BLOCK_GROUP, geo.fr_dblocks, g.fb_grp, g.fb_ptr);
+    const bool cluster = opt.cluster_cited && geo.compact && geo.fr_blocks != 0 && geo.fr_blocks % geo.f64_blocks == 0 &&
+                         geo.fr_rb >= 1024 && !getenv("ET_NO_CLUSTER_SHARES");
+    if (cluster) {
+        g.grp_hint.assign(dfr.block.begin(), dfr.block.begin() + first_dangling_group);
+        g.hint_blocks = geo.fr_blocks;
+    }
+    ds.d64 = deal(geo.f64_blocks, geo.f64_rb / BLOCK_GROUP, geo.f64_dblocks, g.bk_grp, g.bk_ptr);
+    if (cluster) {
+        // sources cited this often by the share's rows stay in front, in position order: nearly every workgroup gathers them
+        const uint32_t hot = getenv("ET_CLUSTER_HOT") ? (uint32_t)atoi(getenv("ET_CLUSTER_HOT")) : 8u;
+        src.cluster_cited(g, dfr.block, geo.fr_blocks, hot, geo.f64_blocks);
+    }
+    return ET_OK;
+}
+
+template <class Src>
+int fill_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned T, const DealtSegment& ds, std::string& err) {
+    const Geometry geo = g.geo;
+    const uint32_t seg_index = geo.seg;
+    const uint32_t G = geo.n_seg, n_active = geo.n_active, n_dangling = geo.n_dangling;
+    const uint32_t target_work = opt.target_work ? opt.target_work : 16384;
+    const std::vector<uint64_t>& in_ptr = ds.in_ptr;
+    const Deal& d64 = ds.d64;
+    const Deal& dfr = ds.dfr;
+    const bool per_row_stream = geo.fr_blocks == 0;      // else the exact variant runs the blocked sweep too
+    std::vector<uint32_t> e_src(per_row_stream ? g.nnz_local : 0);   // source index as the edge records carry it
+    std::vector<uint64_t> e_idx(per_row_stream ? g.nnz_local : 0);   // the edge's value handle
     g.bk_col.resize(g.nnz_local);
     g.bk_row.resize(g.nnz_local);
     if (g.values_are_u32) g.bk_val_u32.resize(g.nnz_local);
@@ -911,7 +1093,6 @@ int lay_out_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned
                 });
         // (c) the workgroups of the exact blocked sweep, when the geometry asks for them
         if (geo.fr_blocks) {
-            const Deal dfr = deal(geo.fr_blocks, geo.fr_rb / BLOCK_GROUP, geo.fr_dblocks, g.fb_grp, g.fb_ptr);
             g.fb_col.resize(g.nnz_local);
             g.fb_row.resize(g.nnz_local);
             g.fb_val.resize(g.nnz_local);
@@ -934,9 +1115,10 @@ int lay_out_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned
         for (int exact = 0; exact < 2; ++exact) {
             const SweepStats ss = sweep_stats(g, exact != 0);
             if (ss.blocks)
-                fprintf(stderr, "[et build] %s sweep: %u workgroups, %llu edges (most %llu, mean %.1f), %llu line fills (most %llu, mean %.1f), clustered %u\n",
+                fprintf(stderr, "[et build] %s sweep: %u workgroups, %llu edges (most %llu, mean %.1f), %llu line fills (most %llu, mean %.1f), clustered %u, widest 64-edge chunk %llu positions\n",
                         exact ? "exact" : "f64", ss.blocks, (unsigned long long)ss.edges, (unsigned long long)ss.edges_most, (double)ss.edges / ss.blocks,
-                        (unsigned long long)ss.line_fills, (unsigned long long)ss.line_fills_most, (double)ss.line_fills / ss.blocks, ss.clustered);
+                        (unsigned long long)ss.line_fills, (unsigned long long)ss.line_fills_most, (double)ss.line_fills / ss.blocks, ss.clustered,
+                        (unsigned long long)ss.chunk_span_most);
         }
     }
     if (geo.n_chunks > 1) {
@@ -1077,6 +1259,14 @@ int lay_out_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned
     return ET_OK;
 }
 
+template <class Src>
+int lay_out_segment(HostGraph& g, const BuildOpts& opt, Src& src, unsigned T, std::string& err) {
+    DealtSegment ds;
+    int rc = deal_segment(g, opt, src, ds);
+    if (rc) return rc;
+    return fill_segment(g, opt, src, T, ds, err);
+}
+
 }  // namespace
 
 SweepStats sweep_stats(const HostGraph& g, bool exact) {
@@ -1091,6 +1281,11 @@ SweepStats sweep_stats(const HostGraph& g, bool exact) {
     for (uint32_t b = 0; b < B; ++b) {
         uint64_t c = 0;
         for (uint64_t k = ptr[b]; k < ptr[b + 1]; ++k) c += k == ptr[b] || (col[k] >> shift) != (col[k - 1] >> shift);
+        // widest range of positions that 64 consecutive edges of a list span (the packed edge records hold a 16-bit offset)
+        for (uint64_t k = ptr[b]; k < ptr[b + 1]; k += 64) {
+            const uint64_t last = std::min<uint64_t>(k + 63, ptr[b + 1] - 1);
+            ss.chunk_span_most = std::max<uint64_t>(ss.chunk_span_most, g.geo.pos_of_col(col[last]) - g.geo.pos_of_col(col[k]));
+        }
         ss.line_fills += c;
         ss.line_fills_most = std::max(ss.line_fills_most, c);
         ss.edges_most = std::max(ss.edges_most, ptr[b + 1] - ptr[b]);
@@ -1106,17 +1301,20 @@ int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index,
     const unsigned T = host_threads();
     AttesterWalk src(pc, g, T);
     if (g.geo.vec_len >= COL_LOCAL_MASK) { err = "more than 2^29 entries in a share's gather vector"; return ET_E_UNSUPPORTED; }
-    return lay_out_segment(g, opt, src, T, err);
+    BuildOpts o = opt;
+    if (getenv("ET_CLUSTER_SHARES")) o.cluster_cited = true;     // measurement knob: such a share steps but cannot pack
+    return lay_out_segment(g, o, src, T, err);
 }
 
 struct SortedRecords {
     RecordWalk walk;
+    DealtSegment dealt;
     SortedRecords(HostGraph& g, unsigned T, const std::vector<uint32_t>& s, const std::vector<uint32_t>& r, const std::vector<uint32_t>& v)
         : walk(g, T, s, r, v) {}
 };
 void free_sorted_records(SortedRecords* r) { delete r; }
 
-int records_to_needs(HostGraph& g, uint32_t seg_index, const std::vector<uint32_t>& src_code, const std::vector<uint32_t>& row,
+int records_to_needs(HostGraph& g, const BuildOpts& opt, uint32_t seg_index, const std::vector<uint32_t>& src_code, const std::vector<uint32_t>& row,
                      const std::vector<uint32_t>& val, SortedRecords** out, std::string& err) {
     if (seg_index >= g.geo.n_seg) { err = "bad segment"; return ET_E_INVALID_ARG; }
     if (!g.values_are_u32) { err = "edge records carry integer opinions only"; return ET_E_UNSUPPORTED; }
@@ -1128,7 +1326,8 @@ int records_to_needs(HostGraph& g, uint32_t seg_index, const std::vector<uint32_
     }
     *out = new SortedRecords(g, host_threads(), src_code, row, val);
     if (g.geo.vec_len >= COL_LOCAL_MASK) { delete *out; *out = nullptr; err = "more than 2^29 entries in a share's gather vector"; return ET_E_UNSUPPORTED; }
-    return ET_OK;
+    // the row groups dealt to the workgroups, and with them the order this share wants the other shares' entries in
+    return deal_segment(g, opt, (*out)->walk, (*out)->dealt);
 }
 
 int plan_segment_from_sorted(HostGraph& g, const BuildOpts& opt, SortedRecords* rec, std::string& err) {
@@ -1136,14 +1335,14 @@ int plan_segment_from_sorted(HostGraph& g, const BuildOpts& opt, SortedRecords* 
     if (g.geo.compact && !g.send_known) { err = "the rows the other shares cite are not known yet"; return ET_E_INVALID_ARG; }
     for (uint32_t c = 0; c < 8; ++c)
         for (uint32_t l : g.send[c]) if (l >= g.geo.rows_cap) { err = "cited row out of range"; return ET_E_OUT_OF_RANGE; }
-    return lay_out_segment(g, opt, rec->walk, rec->walk.T, err);
+    return fill_segment(g, opt, rec->walk, rec->walk.T, rec->dealt, err);
 }
 
 int plan_segment_from_records(HostGraph& g, const BuildOpts& opt, uint32_t seg_index, const std::vector<uint32_t>& src_code,
                               const std::vector<uint32_t>& row, const std::vector<uint32_t>& val, std::string& err) {
     if (g.geo.compact) { err = "a share with a gather vector is laid out in two steps (records_to_needs, plan_segment_from_sorted)"; return ET_E_INVALID_ARG; }
     SortedRecords* rec = nullptr;
-    int rc = records_to_needs(g, seg_index, src_code, row, val, &rec, err);
+    int rc = records_to_needs(g, opt, seg_index, src_code, row, val, &rec, err);
     if (rc) return rc;
     rc = plan_segment_from_sorted(g, opt, rec, err);
     delete rec;

@@ -41,6 +41,10 @@ struct BuildOpts {
     uint32_t hot_prefix = 16384; // the most-attesting (most gathered) peers take the first positions: one contiguous prefix of the vector
     uint32_t f64_blocks = 256;   // workgroups of the f64 variant (one per CU)
     uint32_t n_chunks = 1;       // pieces a segment is exchanged in (see Geometry::n_chunks); honoured where both variants run the blocked sweep
+    // gather vectors: the other shares' entries ordered by the workgroup that cites them (order_cited_sources in builder.cpp)
+    // instead of ascending.  The shares that pack for this one must then be told the order (HostGraph::need): set by the
+    // callers that deliver it (the one-thread driver, the rank-local plan).
+    bool cluster_cited = false;
     bool full_vector = false;    // several shares: keep every share's whole segment in the vectors (all-gather exchange) instead of the cited entries only
     // Relative time a workgroup on XCD x (workgroup b runs on XCD b mod 8) needs per edge of a blocked sweep, in 1/1024
     // (1024 = the same everywhere): the deal levels edges x cost instead of edges.  Measured per device by
@@ -100,6 +104,7 @@ struct HostGraph {
     std::vector<uint32_t> need[8], send[8];
     bool send_known = false;
     uint32_t blk_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // first entry of block p (the share's own block is [0, seg_stride()))
+    uint32_t xcd_cost[8] = {1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024};   // what the deals were levelled with
 };
 
 // Returns 0 or a negative ET_E_* code; `err` receives a human-readable reason.
@@ -136,12 +141,13 @@ void fill_factors_u64(HostGraph& g, const uint32_t* peers, uint32_t count, const
 int plan_segment_from_records(HostGraph& g, const BuildOpts& opt, uint32_t seg, const std::vector<uint32_t>& src_code,
                               const std::vector<uint32_t>& row, const std::vector<uint32_t>& val, std::string& err);
 // With a gather vector the other shares must learn which of their rows this share cites before they can pack them: the same
-// in two steps.  records_to_needs sorts the records and fills g.need (and the geometry of the gather vector); the caller
+// in two steps.  records_to_needs sorts the records, deals the row groups to the workgroups (opt.xcd_cost must be final) and
+// fills g.need (and the geometry of the gather vector); the caller
 // delivers need[p] to share p and stores what the others want from this share in g.send (g.send_known = true);
 // plan_segment_from_sorted then lays out the share.  (Position-order layouts: need stays empty, nothing to deliver.)
 struct SortedRecords;
 void free_sorted_records(SortedRecords* r);
-int records_to_needs(HostGraph& g, uint32_t seg, const std::vector<uint32_t>& src_code, const std::vector<uint32_t>& row,
+int records_to_needs(HostGraph& g, const BuildOpts& opt, uint32_t seg, const std::vector<uint32_t>& src_code, const std::vector<uint32_t>& row,
                      const std::vector<uint32_t>& val, SortedRecords** out, std::string& err);
 int plan_segment_from_sorted(HostGraph& g, const BuildOpts& opt, SortedRecords* rec, std::string& err);
 // steps 1-4 alone (filter, last write wins, row sums, degrees) over the attestations given
@@ -154,7 +160,7 @@ int filter_edges(const BuildInput& in, PlanCommon& pc, RowSums& sums, PeerStats&
 
 // Lines of the vector one launch of a blocked sweep pulls into the L1s: distinct (workgroup, 128-byte line) pairs of the
 // sorted per-workgroup lists (f64: 16 entries per line; exact: 4).  blocks = 0 when the plan holds no such lists.
-struct SweepStats { uint32_t blocks = 0, clustered = 0; uint64_t edges = 0, edges_most = 0, line_fills = 0, line_fills_most = 0; };
+struct SweepStats { uint32_t blocks = 0, clustered = 0; uint64_t edges = 0, edges_most = 0, line_fills = 0, line_fills_most = 0, chunk_span_most = 0; };
 SweepStats sweep_stats(const HostGraph& g, bool exact);
 
 // host threads for the scatter passes over the edges (the GPU boxes give a process 16 CPUs)

@@ -64,6 +64,14 @@ int et_device_count(void) {
     return n;
 }
 
+// the caller's per-XCD cost factors, if it gave any (all zero = measure on the device, or uniform without one)
+static bool given_xcd_cost(const et_build_opts* opts, BuildOpts& bo) {
+    bool any = false;
+    for (int x = 0; opts && x < 8; ++x) any = any || opts->xcd_cost[x] != 0;
+    for (int x = 0; any && x < 8; ++x) bo.xcd_cost[x] = opts->xcd_cost[x] ? opts->xcd_cost[x] : 1024u;
+    return any;
+}
+
 static void read_opts(const et_build_opts* opts, BuildOpts& bo, int& variants, int& device) {
     variants = 0;
     device = -1;
@@ -111,7 +119,7 @@ static int plan_build(uint32_t n, const uint8_t* member, uint64_t n_edges, const
     int variants, device;
     read_opts(opts, bo, variants, device);
     read_env(bo);
-    if (for_device) xcd_cost_factors(device, bo.xcd_cost);
+    if (!given_xcd_cost(opts, bo) && for_device) xcd_cost_factors(device, bo.xcd_cost);
     std::unique_ptr<et_plan> p(new et_plan());
     std::string err;
     int rc = build_graph(in, bo, p->h, err);
@@ -132,6 +140,7 @@ static void fill_info(const HostGraph& h, et_graph_info* info) {
     info->full_len = (uint64_t)h.geo.n_seg * h.geo.seg_stride();
     info->gather = h.geo.compact;
     info->n_chunks = h.geo.n_chunks; info->chunk_rows = h.geo.chunk_rows;
+    for (int x = 0; x < 8; ++x) info->xcd_cost[x] = h.xcd_cost[x];
 }
 int et_plan_info_get(const et_plan* p, et_graph_info* info) {
     if (!p || !info) return ET_E_INVALID_ARG;
@@ -161,6 +170,7 @@ int et_plan_sweep_stats(const et_plan* p, int variant, et_sweep_stats* out) {
     out->blocks = ss.blocks; out->clustered = ss.clustered;
     out->edges = ss.edges; out->edges_most = ss.edges_most;
     out->line_fills = ss.line_fills; out->line_fills_most = ss.line_fills_most;
+    out->chunk_span_most = ss.chunk_span_most;
     return ET_OK;
 }
 int et_graph_from_plan(const et_plan* p, const et_build_opts* opts, et_graph** out) {
@@ -199,6 +209,7 @@ int et_graph_info_get(const et_graph* g, et_graph_info* info) {
     info->exact_sweep_blocks = d->fr_blocked ? d->geo.fr_blocks : 0;
     info->n_chunks = d->geo.n_chunks; info->chunk_rows = d->geo.chunk_rows;
     info->gather = d->geo.compact; info->full_len = d->full_len;
+    for (int x = 0; x < 8; ++x) info->xcd_cost[x] = d->xcd_cost[x];
     return ET_OK;
 }
 

@@ -26,6 +26,7 @@ struct et_dplan {
     std::vector<uint32_t> from, to, val; // copies of the local attestations (the caller's arrays need not outlive stage 1)
     BuildOpts opt;
     int variants = 0, device = -1;
+    bool xcd_given = false;              // the caller named the per-XCD cost factors: no probe
     int stage = 1;
     // stage 2: records by destination share
     std::vector<uint64_t> out_begin;     // n_seg + 1
@@ -98,6 +99,8 @@ int et_dplan_set_global_stats(et_dplan* p, const uint64_t* row_sum, const uint32
     if (opts->target_work) bo.target_work = opts->target_work;
     if (opts->n_chunks) bo.n_chunks = opts->n_chunks;
     bo.full_vector = (opts->flags & ET_BUILD_FULL_VECTOR) != 0;
+    for (int x = 0; x < 8; ++x) p->xcd_given = p->xcd_given || opts->xcd_cost[x] != 0;
+    for (int x = 0; p->xcd_given && x < 8; ++x) bo.xcd_cost[x] = opts->xcd_cost[x] ? opts->xcd_cost[x] : 1024u;
     if (bo.seg >= bo.n_seg) { set_error("bad segment"); return ET_E_INVALID_ARG; }
     p->opt = bo;
     p->variants = (int)opts->variants;
@@ -219,6 +222,7 @@ int et_dplan_info_get(const et_dplan* p, et_graph_info* info) {
     info->full_len = (uint64_t)h.geo.n_seg * h.geo.seg_stride();
     info->gather = h.geo.compact;
     info->n_chunks = h.geo.n_chunks; info->chunk_rows = h.geo.chunk_rows;
+    for (int x = 0; x < 8; ++x) info->xcd_cost[x] = p->opt.xcd_cost[x];
     return ET_OK;
 }
 
@@ -227,8 +231,11 @@ static int seal_records(et_dplan* p) {
     if (p->stage == 3) return ET_OK;
     if (p->stage != 2) { set_error("the records are complete between set_global_stats and finish"); return ET_E_INVALID_ARG; }
     p->out_src = std::vector<uint32_t>(); p->out_row = std::vector<uint32_t>(); p->out_val = std::vector<uint32_t>();
+    // the deal levels edges x the XCDs' cost: measured now where the caller named the device the share will run on
+    if (!p->xcd_given && p->device >= 0) xcd_cost_factors(p->device, p->opt.xcd_cost);
+    p->opt.cluster_cited = true;         // the order this share asks in reaches the others through et_dplan_needs
     std::string err;
-    int rc = records_to_needs(p->pc.g, p->opt.seg, p->in_src, p->in_row, p->in_val, &p->sorted, err);
+    int rc = records_to_needs(p->pc.g, p->opt, p->opt.seg, p->in_src, p->in_row, p->in_val, &p->sorted, err);
     if (rc) { set_error(err); return rc; }
     p->in_src = std::vector<uint32_t>(); p->in_row = std::vector<uint32_t>(); p->in_val = std::vector<uint32_t>();
     p->told.assign(p->pc.g.geo.n_seg, 0);
@@ -273,7 +280,7 @@ static int lay_out(et_dplan* p, bool for_device) {
             if (!p->told[c]) { set_error("et_dplan_add_wanted has not been called for every other share"); return ET_E_INVALID_ARG; }
         g.send_known = true;
     }
-    if (for_device) xcd_cost_factors(p->device, p->opt.xcd_cost);
+    (void)for_device;
     std::string err;
     rc = plan_segment_from_sorted(g, p->opt, p->sorted, err);
     if (rc) { set_error(err); return rc; }

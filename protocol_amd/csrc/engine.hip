@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -150,11 +151,13 @@ ET_DEV double wave_sum_f64(double v) {
 // VT = double: weighted form.
 // PACKED (byte opinions): 5 bytes per edge.  A workgroup's list is sorted by source, so the 64
 // consecutive edges one wavefront loads together span a narrow range: the record holds the
-// accumulator slot (low 16 bits) and the source position minus the position of the chunk's first
-// source (high 16 bits), and one base position per 64 edges sits in a side array.
+// accumulator slot (its low rec_shift bits: as many as the workgroup's slots need) and the source
+// position minus the position of the chunk's first source (the bits above), and one base position
+// per 64 edges sits in a side array.
 // ---------------------------------------------------------------------------------------------
 struct StepArgsF64B {
-    const uint32_t* rec;      // PACKED: [edge] slot | (source - chunk base) << 16
+    const uint32_t* rec;      // PACKED: [edge] slot | (source - chunk base) << rec_shift
+    uint32_t rec_shift;
     const uint32_t* cbase;    // PACKED: base position per chunk of 64 edges, workgroup b's chunks start at cptr[b]
     const uint64_t* cptr;
     const uint64_t* bk_ptr;
@@ -254,6 +257,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     int since_bar = (int)a.bar_period - (int)max(a.bar_period, (n_batches * a.bar_first_256) >> 8);
     if (PACKED) {
         const uint32_t* __restrict__ cb = a.cbase + a.cptr[b];
+        const uint32_t rec_shift = a.rec_shift, rec_mask = (1u << rec_shift) - 1u;
         uint32_t chunk = wave;                             // (e - e0) / 64
         for (uint32_t k = 0; k < n_batches; ++k, e += U * 1024, chunk += U * 16) {
             uint32_t rc[U], base[U];
@@ -261,9 +265,9 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) { rc[u] = a.rec[e + u * 1024]; w[u] = (double)wr[e + u * 1024]; base[u] = cb[chunk + u * 16]; }
 #pragma unroll
-            for (int u = 0; u < U; ++u) xv[u] = xr[(size_t)base[u] + (rc[u] >> 16)];
+            for (int u = 0; u < U; ++u) xv[u] = xr[(size_t)base[u] + (rc[u] >> rec_shift)];
 #pragma unroll
-            for (int u = 0; u < U; ++u) atomicAdd(&acc_l[rc[u] & 0xFFFFu], w[u] * xv[u]);
+            for (int u = 0; u < U; ++u) atomicAdd(&acc_l[rc[u] & rec_mask], w[u] * xv[u]);
             if (++since_bar == (int)a.bar_period) { since_bar = 0; __syncthreads(); }
         }
         {   // the rest of the list (fewer than U * 1024 edges) as one more batch, its loads in flight together like the
@@ -279,10 +283,10 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
                 base[u] = in[u] ? cb[chunk + u * 16] : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) xv[u] = in[u] ? xr[(size_t)base[u] + (rc[u] >> 16)] : 0.0;
+            for (int u = 0; u < U; ++u) xv[u] = in[u] ? xr[(size_t)base[u] + (rc[u] >> rec_shift)] : 0.0;
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (in[u]) atomicAdd(&acc_l[rc[u] & 0xFFFFu], w[u] * xv[u]);
+                if (in[u]) atomicAdd(&acc_l[rc[u] & rec_mask], w[u] * xv[u]);
         }
     } else {
         for (uint32_t k = 0; k < n_batches; ++k, e += U * 1024) {
@@ -717,7 +721,8 @@ struct StepArgsFrB {
     const uint32_t* col;
     const uint16_t* row;
     const uint8_t* val;
-    // packed records (see k_step_f64_blocked): accumulator row | (source position - base of the 64-edge chunk) << 16
+    // packed records (see k_step_f64_blocked): accumulator row | (source position - base of the 64-edge chunk) << rec_shift
+    uint32_t rec_shift;
     const uint32_t* rec;
     const uint32_t* cbase;
     const uint64_t* cptr;
@@ -863,8 +868,8 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             vv = a.val[i];
             if (PACKED) {
                 const uint32_t rc = a.rec[i];
-                cc = cb[(i - e0) >> 6] + (rc >> 16);
-                rr = rc & 0xFFFFu;
+                cc = cb[(i - e0) >> 6] + (rc >> a.rec_shift);
+                rr = rc & ((1u << a.rec_shift) - 1u);
             } else {
                 cc = a.col[i];
                 rr = a.row[i];
@@ -908,8 +913,8 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
                 v[u] = a.val[i];
                 if (PACKED) {
                     const uint32_t rc = a.rec[i];
-                    c[u] = a.cbase[a.cptr[b] + ((i - e0) >> 6)] + (rc >> 16);
-                    r[u] = rc & 0xFFFFu;
+                    c[u] = a.cbase[a.cptr[b] + ((i - e0) >> 6)] + (rc >> a.rec_shift);
+                    r[u] = rc & ((1u << a.rec_shift) - 1u);
                 } else {
                     c[u] = a.col[i];
                     r[u] = a.row[i];
@@ -1156,12 +1161,14 @@ static U256 to_u256(const FrRaw& r) {
     return u;
 }
 
-// Packs a blocked sweep's (source, row) pairs into one 32-bit record each: row | (position - base) << 16, with one base
-// position per 64 consecutive edges of a workgroup's list (the lists ascend by position).  False when some chunk spans
-// more than 65535 positions.
-static bool pack_records(const Geometry& geo, uint32_t B, const std::vector<uint64_t>& ptr, const std::vector<uint32_t>& col,
+// Packs a blocked sweep's (source, row) pairs into one 32-bit record each: row | (position - base) << shift, with one base
+// position per 64 consecutive edges of a workgroup's list (the lists ascend by position) and `shift` = the bits the
+// workgroup's accumulator slots need.  False when some chunk spans more positions than the remaining bits hold.
+static uint32_t slot_bits(uint32_t slots) { uint32_t b = 1; while ((1u << b) < slots) ++b; return b; }
+static bool pack_records(const Geometry& geo, uint32_t B, uint32_t shift, const std::vector<uint64_t>& ptr, const std::vector<uint32_t>& col,
                          const std::vector<uint16_t>& row, std::vector<uint64_t>& cptr, std::vector<uint32_t>& cbase,
                          std::vector<uint32_t>& rec) {
+    const uint32_t span_max = (uint32_t)((1ull << (32 - shift)) - 1);
     cptr.assign((size_t)B + 1, 0);
     for (uint32_t b = 0; b < B; ++b) cptr[b + 1] = cptr[b] + (ptr[b + 1] - ptr[b] + 63) / 64;
     cbase.assign(cptr[B], 0);
@@ -1175,8 +1182,8 @@ static bool pack_records(const Geometry& geo, uint32_t B, const std::vector<uint
                 const uint32_t pos = geo.pos_of_col(col[q]);
                 const uint64_t rel = q - ptr[b];
                 if ((rel & 63) == 0) { base = pos; cbase[cptr[b] + rel / 64] = base; }
-                if (pos - base > 0xFFFFu) fits = false;
-                rec[q] = (uint32_t)row[q] | ((pos - base) << 16);
+                if (pos - base > span_max || ((uint32_t)row[q] >> shift) != 0) fits = false;
+                rec[q] = (uint32_t)row[q] | ((pos - base) << shift);
             }
         }
     });
@@ -1214,40 +1221,60 @@ void xcd_cost_factors(int device, uint32_t out[8]) {
     for (int x = 0; x < 8; ++x) out[x] = 1024;
     if (const char* e = getenv("ET_XCD_BALANCE")) if (atoi(e) == 0) return;
     std::lock_guard<std::mutex> guard(lock);
-    if (device < 0 && hipGetDevice(&device) != hipSuccess) return;
+    int previous = -1;
+    if (hipGetDevice(&previous) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (device < 0) device = previous;
     auto hit = cache.find(device);
     if (hit != cache.end()) { for (int x = 0; x < 8; ++x) out[x] = hit->second[x]; return; }
     std::array<uint32_t, 8> f;
     f.fill(1024);
-    const uint32_t n_entries = 1u << 20, blocks = 256, passes = 64, reps = 6;
+    // The probe assumes what it measures: one workgroup per compute unit, workgroup b on XCD b mod 8.  A card that is
+    // partitioned or is another part (other CU or XCD counts) keeps the uniform factors.
+    int cus = 0, xccs = 0;
+    bool ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
+              hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, device) == hipSuccess && cus == 256 && xccs == 8;
+    const uint32_t n_entries = 1u << 20, blocks = 256, passes = 64, reps = 7;
     uint4* tab = nullptr;
     unsigned long long* d_ticks = nullptr;
     uint32_t* d_sink = nullptr;
-    bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(&tab, (size_t)n_entries * 32) == hipSuccess &&
-              hipMalloc(&d_ticks, blocks * sizeof(unsigned long long)) == hipSuccess && hipMalloc(&d_sink, 64) == hipSuccess &&
-              hipMemset(tab, 1, (size_t)n_entries * 32) == hipSuccess;
-    double per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    ok = ok && hipSetDevice(device) == hipSuccess && hipMalloc(&tab, (size_t)n_entries * 32) == hipSuccess &&
+         hipMalloc(&d_ticks, blocks * sizeof(unsigned long long)) == hipSuccess && hipMalloc(&d_sink, 64) == hipSuccess &&
+         hipMemset(tab, 1, (size_t)n_entries * 32) == hipSuccess;
+    // two halves of the launches, each ranked on its own: factors are applied only when both halves rank the XCDs alike
+    // (a card shared with another job, or clocks settling, give rankings that do not repeat)
+    double half[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
     for (uint32_t r = 0; ok && r < reps; ++r) {
         hipLaunchKernelGGL(k_xcd_probe, dim3(blocks), dim3(1024), 0, 0, tab, n_entries, passes, d_ticks, d_sink);
         std::vector<unsigned long long> t(blocks);
         ok = hipMemcpy(t.data(), d_ticks, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
         if (ok && r > 0)                                   // the first launch warms the table into the caches
-            for (uint32_t b = 0; b < blocks; ++b) per_xcd[b % 8] += (double)t[b];
+            for (uint32_t b = 0; b < blocks; ++b) half[(r - 1) & 1][b % 8] += (double)t[b];
     }
     if (tab) (void)hipFree(tab);
     if (d_ticks) (void)hipFree(d_ticks);
     if (d_sink) (void)hipFree(d_sink);
     if (ok) {
-        double lo = per_xcd[0], hi = per_xcd[0];
+        double per_xcd[8], lo = 0, hi = 0, mean = 0;
+        for (int x = 0; x < 8; ++x) { per_xcd[x] = half[0][x] + half[1][x]; mean += per_xcd[x] / 8; }
+        lo = hi = per_xcd[0];
         for (int x = 1; x < 8; ++x) { lo = std::min(lo, per_xcd[x]); hi = std::max(hi, per_xcd[x]); }
-        if (lo > 0 && hi / lo >= 1.01 && hi / lo <= 1.25)
+        // the same XCDs above and below the mean in both halves
+        bool repeats = true;
+        for (int h = 0; h < 2; ++h) {
+            double m = 0;
+            for (int x = 0; x < 8; ++x) m += half[h][x] / 8;
+            for (int x = 0; x < 8; ++x)
+                if (std::fabs(per_xcd[x] - mean) > 0.005 * mean && (half[h][x] > m) != (per_xcd[x] > mean)) repeats = false;
+        }
+        if (repeats && lo > 0 && hi / lo >= 1.01 && hi / lo <= 1.25)
             for (int x = 0; x < 8; ++x) f[x] = (uint32_t)(1024.0 * per_xcd[x] / lo + 0.5);
     }
     (void)hipGetLastError();
+    if (previous >= 0) (void)hipSetDevice(previous);       // the caller's current device stays what it was
     cache[device] = f;
     for (int x = 0; x < 8; ++x) out[x] = f[x];
-    if (getenv("ET_XCD_VERBOSE"))
-        fprintf(stderr, "xcd cost factors (device %d): %u %u %u %u %u %u %u %u\n", device, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+    if (getenv("ET_XCD_VERBOSE") || getenv("ET_BUILD_STATS"))
+        fprintf(stderr, "[et build] xcd cost factors (device %d, %d CUs, %d XCDs): %u %u %u %u %u %u %u %u\n", device, cus, xccs, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
 }
 
 // Where a sweep's barriers start.  The barriers hold the sixteen wavefronts of a workgroup inside one window of the vector
@@ -1295,6 +1322,7 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     g->fr_blocked = h.geo.fr_blocks != 0 && !h.fb_ptr.empty();
     g->n_fr_parts = g->fr_blocked ? h.geo.fr_blocks : g->n_work;
     g->pos_of_ext = h.pos_of_ext;
+    for (int x = 0; x < 8; ++x) g->xcd_cost[x] = h.xcd_cost[x];
     g->inv_nm1_w = h.inv_nm1_w;
     g->inv_nm1 = 1.0 / (double)(h.n_valid - 1);
     uint64_t& tot = g->device_bytes;
@@ -1356,7 +1384,8 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
         if (can_pack && !getenv("ET_F64_UNPACKED")) {
             std::vector<uint64_t> cptr;
             std::vector<uint32_t> cbase, rec;
-            if (pack_records(h.geo, h.geo.f64_blocks, h.bk_ptr, h.bk_col, h.bk_row, cptr, cbase, rec)) {
+            g->f64_rec_shift = slot_bits(h.geo.f64_rb);
+            if (pack_records(h.geo, h.geo.f64_blocks, g->f64_rec_shift, h.bk_ptr, h.bk_col, h.bk_row, cptr, cbase, rec)) {
                 g->packed = true;
                 if ((rc = dev_upload(&g->d_bk_rec, rec, tot)) || (rc = dev_upload(&g->d_bk_cbase, cbase, tot)) ||
                     (rc = dev_upload(&g->d_bk_cptr, cptr, tot))) return rc;
@@ -1418,7 +1447,8 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
             if (can_pack && h.geo.fr_compact && !getenv("ET_FR_UNPACKED")) {
                 std::vector<uint64_t> cptr;
                 std::vector<uint32_t> cbase, rec;
-                if (pack_records(h.geo, h.geo.fr_blocks, h.fb_ptr, h.fb_col, h.fb_row, cptr, cbase, rec)) {
+                g->fr_rec_shift = slot_bits(h.geo.fr_rb);
+                if (pack_records(h.geo, h.geo.fr_blocks, g->fr_rec_shift, h.fb_ptr, h.fb_col, h.fb_row, cptr, cbase, rec)) {
                     g->fr_packed = true;
                     if ((rc = dev_upload(&g->d_fb_rec, rec, tot)) || (rc = dev_upload(&g->d_fb_cbase, cbase, tot)) ||
                         (rc = dev_upload(&g->d_fb_cptr, cptr, tot))) return rc;
@@ -1443,20 +1473,17 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
         const Geometry& geo = h.geo;
         const uint32_t own_len = geo.seg_stride();
         if (geo.compact) {
-            if (!h.send_known) { set_error("the rows the other shares cite are not known"); return ET_E_INVALID_ARG; }
-            std::vector<uint32_t> idx;
             for (uint32_t c = 0; c < geo.n_seg; ++c) {
                 if (c == geo.seg) continue;
-                g->send_off[c] = (uint32_t)idx.size();
-                idx.insert(idx.end(), h.send[c].begin(), h.send[c].end());
-                for (uint32_t k = 0; k < geo.nd_cap; ++k) idx.push_back(geo.rows_cap + k);
-                g->send_cnt[c] = (uint32_t)idx.size() - g->send_off[c];
                 g->recv_off[c] = h.blk_off[c];
                 g->recv_cnt[c] = (uint32_t)h.need[c].size() + geo.nd_cap;
             }
-            for (uint32_t v : idx) if (v >= own_len) { set_error("internal: packed entry outside the own block"); return ET_E_INVALID_ARG; }
-            g->send_total = idx.size();
-            if ((rc = dev_upload(&g->d_send_idx, idx, tot))) return rc;
+            // what the other shares cite here: known now, or told later (set_send_lists) by whoever lays out all shares
+            if (h.send_known) {
+                const std::vector<uint32_t>* lists[8];
+                for (int c = 0; c < 8; ++c) lists[c] = &h.send[c];
+                if ((rc = g->set_send_lists(lists))) return rc;
+            }
         } else {
             for (uint32_t c = 0; c < geo.n_seg; ++c) {
                 if (c == geo.seg) continue;
@@ -1480,6 +1507,10 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     HIP_TRY(hipDeviceSynchronize());
     free_tmp();
     free_all();
+    if (getenv("ET_BUILD_STATS"))
+        fprintf(stderr, "[et upload] edge records: f64 %s, exact %s; vectors of %zu entries (%zu in position order), %.2f GB on the device\n",
+                g->packed ? "packed (5 bytes)" : "source, slot, opinion apart", !g->fr_blocked ? "per-row stream" : (g->fr_packed ? "packed (5 bytes)" : "source, slot, opinion apart"),
+                g->vec_len, g->full_len, (double)g->device_bytes / 1e9);
     *out = g.release();
     return ET_OK;
 }
@@ -1515,7 +1546,7 @@ int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double
     const size_t ring = (size_t)(iteration % STATS_RING) * n_f64_parts;
     StepArgsF64B a;
     a.bk_ptr = d_bk_ptr; a.grp = d_bk_grp; a.col = d_bk_col; a.w = d_bk_w; a.row = d_bk_row; a.x = x; a.y = y; a.pretrust = pretrust;
-    a.rec = d_bk_rec; a.cbase = d_bk_cbase; a.cptr = d_bk_cptr;
+    a.rec = d_bk_rec; a.cbase = d_bk_cbase; a.cptr = d_bk_cptr; a.rec_shift = f64_rec_shift;
     a.own = own64; a.scale = d_scale64;
     a.res_part = d_res_part + ring; a.sum_part = d_sum_part + ring;
     a.geo = geo; a.inv_nm1 = inv_nm1; a.alpha = alpha; a.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u;
@@ -1545,7 +1576,7 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
         StepArgsFrB fb;
         const size_t ringb = (size_t)(iteration % STATS_RING) * n_fr_parts;
         fb.ptr = d_fb_ptr; fb.grp = d_fb_grp; fb.col = d_fb_col; fb.row = d_fb_row; fb.val = d_fb_val; fb.x = x; fb.y = y;
-        fb.rec = d_fb_rec; fb.cbase = d_fb_cbase; fb.cptr = d_fb_cptr;
+        fb.rec = d_fb_rec; fb.cbase = d_fb_cbase; fb.cptr = d_fb_cptr; fb.rec_shift = fr_rec_shift;
         fb.own = own_fr; fb.scale288 = d_fb_scale; fb.sum_part = d_frsum_part + 2 * ringb; fb.chg_part = d_chg_part + ringb;
         fb.geo = geo; fb.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u; fb.inv_nm1_w = to_u256(inv_nm1_w);
         fb.inv_nm1_w576 = to_u256((Fr::from_raw(inv_nm1_w) * Fr::one().pow2k(288)).to_raw());
@@ -1624,8 +1655,34 @@ int DeviceGraph::stats_fr(uint32_t iteration, hipStream_t st, et_iter_stats* out
     return ET_OK;
 }
 
+int DeviceGraph::set_send_lists(const std::vector<uint32_t>* const lists[8]) {
+    if (!geo.compact) { set_error("only a share with a gather vector packs"); return ET_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t own_len = geo.seg_stride();
+    std::vector<uint32_t> idx;
+    for (uint32_t c = 0; c < geo.n_seg; ++c) {
+        send_off[c] = send_cnt[c] = 0;
+        if (c == geo.seg) continue;
+        send_off[c] = (uint32_t)idx.size();
+        for (uint32_t v : *lists[c]) {
+            if (v >= geo.rows_cap) { set_error("cited row outside this share's rows"); return ET_E_OUT_OF_RANGE; }
+            idx.push_back(v);
+        }
+        for (uint32_t k = 0; k < geo.nd_cap; ++k) idx.push_back(geo.rows_cap + k);   // the partial sums travel with every piece
+        send_cnt[c] = (uint32_t)idx.size() - send_off[c];
+    }
+    (void)own_len;
+    if (d_send_idx) { (void)hipFree(d_send_idx); d_send_idx = nullptr; }
+    int rc = dev_upload(&d_send_idx, idx, device_bytes);
+    if (rc) return rc;
+    send_total = idx.size();
+    send_known = true;
+    return ET_OK;
+}
+
 int DeviceGraph::pack(const void* y, void* send, size_t elem, hipStream_t st) {
     if (!y || !send || (elem != 8 && elem != 32)) return ET_E_INVALID_ARG;
+    if (geo.compact && !send_known) { set_error("this share was not told which of its rows the other shares cite"); return ET_E_UNSUPPORTED; }
     if (!geo.compact) {       // position order: a share's segment is what it sends
         if (send_total) HIP_TRY(hipMemcpyAsync(send, static_cast<const char*>(y) + (size_t)geo.own_off * elem, send_total * elem, hipMemcpyDeviceToDevice, st));
         return ET_OK;

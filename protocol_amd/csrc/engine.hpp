@@ -35,6 +35,7 @@ struct DeviceGraph {
     FrRaw inv_nm1_w{};
     double inv_nm1 = 0.0;
     uint32_t last_iters = 0;
+    uint32_t xcd_cost[8] = {1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024};   // what the layout was levelled with
 
     WorkDesc* d_work = nullptr;
     SliceDesc* d_slices = nullptr;
@@ -60,6 +61,7 @@ struct DeviceGraph {
     // where the sweeps' barriers start and how often they come (see sweep_barriers in engine.hip)
     uint32_t f64_bar_period = 2, f64_bar_first_256 = 0, fr_bar_period = 8, fr_bar_first_256 = 0;
     bool packed = false;
+    uint32_t f64_rec_shift = 16, fr_rec_shift = 16;   // bits of a packed record that hold the accumulator slot
     uint32_t* d_bk_rec = nullptr;
     uint32_t* d_bk_cbase = nullptr;
     uint64_t* d_bk_cptr = nullptr;
@@ -102,6 +104,7 @@ struct DeviceGraph {
     uint32_t* d_send_idx = nullptr;
     uint32_t send_off[8] = {}, send_cnt[8] = {}, recv_off[8] = {}, recv_cnt[8] = {};
     uint64_t send_total = 0;
+    bool send_known = false;          // gather vector: the rows the other shares cite have been set
     // ring of HIP event pairs bracketing the iteration launches of timed runs
     static const uint32_t EVENT_RING = 1024;
     std::vector<void*> ev_begin, ev_end;
@@ -124,6 +127,8 @@ struct DeviceGraph {
     int run_fr(uint32_t iters, uint64_t lo, uint64_t hi, hipStream_t st, bool record);
     // copies the entries the other shares cite out of the own block of y into `send` (elem = 8 or 32 bytes per entry)
     int pack(const void* y, void* send, size_t elem, hipStream_t st);
+    // gather vector: lists[c] = the local rows of this share that share c cites, in c's order (replaces earlier lists)
+    int set_send_lists(const std::vector<uint32_t>* const lists[8]);
     int record_begin(hipStream_t st);
     int record_end(hipStream_t st);
     int event_times(float* total_ms, uint32_t* pairs);

@@ -354,13 +354,26 @@ int et_sharded_create(uint32_t n, const uint8_t* member, uint64_t n_edges, const
     s->n = n;
     s->n_valid = pc.g.n_valid;
     s->g.assign(n_devices, nullptr);
+    // gather vectors: need[r][p] = the rows of share p that share r cites, in the order r asked for; share p packs them
+    std::vector<std::vector<std::vector<uint32_t>>> need(n_devices);
+    bo.cluster_cited = true;                             // every share is laid out here: each is told the others' orders below
     for (uint32_t r = 0; r < n_devices; ++r) {
         HostGraph h;
         BuildOpts bs = bo;
         xcd_cost_factors(devices[r], bs.xcd_cost);      // each share levelled for the XCDs of the card it runs on
         if ((rc = plan_segment(pc, bs, r, h, err))) { set_error(err); return rc; }
+        h.send_known = false;                            // set below, from the other shares' plans
         if ((rc = DeviceGraph::create(h, s->variants, devices[r], &s->g[r]))) return rc;
+        need[r].resize(n_devices);
+        for (uint32_t p = 0; p < n_devices; ++p) need[r][p].swap(h.need[p]);
     }
+    if (s->g[0]->geo.compact)
+        for (uint32_t p = 0; p < n_devices; ++p) {
+            const std::vector<uint32_t>* lists[8];
+            static const std::vector<uint32_t> none;
+            for (uint32_t c = 0; c < 8; ++c) lists[c] = c < n_devices && c != p ? &need[c][p] : &none;
+            if ((rc = s->g[p]->set_send_lists(lists))) return rc;
+        }
     s->vec_len = s->g[0]->vec_len;              // position order: the same on every share; gather vectors: see g[r]->vec_len
     s->gather = s->g[0]->geo.compact != 0;
     s->seg_stride = s->g[0]->geo.seg_stride();

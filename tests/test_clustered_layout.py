@@ -99,6 +99,42 @@ def test_the_clustered_plan_does_not_depend_on_the_number_of_host_threads(graph,
     assert one.sweep == many.sweep
 
 
+def test_two_shares_ask_for_the_cited_entries_grouped_by_workgroup():
+    """Gather vectors of shares laid out from edge records (et_dplan_*): each share asks for the other share's entries in the
+    order its workgroups want them.  Against the shares et_plan_build lays out from the whole list, which ask in ascending
+    order: the same entries, the same geometry, level workgroups, fewer lines per launch -- and what one share says it needs
+    is what the other is told to pack."""
+    n, m, world = 1 << 20, 1 << 24, 2
+    frm, to, val = pa.synth_graph(3, n, m, seed=5, value_max=255)
+    plans = [pa.DistributedPlan(n, frm[frm % world == r], to[frm % world == r], val[frm % world == r]) for r in range(world)]
+    stats = [p.local_stats() for p in plans]
+    for r, p in enumerate(plans):
+        p.set_global_stats(sum(s[0] for s in stats), sum(s[1] for s in stats), sum(s[2] for s in stats), sum(s[3] for s in stats),
+                           max(s[4] for s in stats), world, r)
+    for r, p in enumerate(plans):
+        for q in plans:
+            p.add_incoming(*q.outgoing(r))
+    needs = {(r, q): p.needs(q).copy() for r, p in enumerate(plans) for q in range(world) if q != r}
+    for (r, q), rows in needs.items():
+        plans[q].add_wanted(r, rows)
+    for r, p in enumerate(plans):
+        got = p.finish_host()
+        ref = pa.Plan(n, frm, to, value_u32=val, n_seg=world, seg=r)
+        q = 1 - r
+        assert got.exchange.gather == ref.exchange.gather == 1
+        assert list(got.exchange.recv_off) == list(ref.exchange.recv_off) and list(got.exchange.recv_count) == list(ref.exchange.recv_count)
+        assert list(got.exchange.send_count) == list(ref.exchange.send_count)
+        assert np.array_equal(got.need[q], needs[(r, q)]) and np.array_equal(got.send[q], needs[(q, r)])
+        # the same entries in another order
+        assert not np.array_equal(got.need[q], ref.need[q]) and np.array_equal(np.sort(got.need[q]), ref.need[q])
+        for variant in ("f64", "fr"):
+            a, b = ref.sweep[variant], got.sweep[variant]
+            assert a["blocks"] == b["blocks"] and a["edges"] == b["edges"]
+            assert b["clustered"] == 1 and a["clustered"] == 0
+            assert b["edges_most"] <= 1.01 * b["edges"] / b["blocks"]
+            assert b["line_fills"] < 0.9 * a["line_fills"], (variant, a, b)
+
+
 def test_sweep_stats_refuses_bad_arguments():
     import ctypes as C
     from protocol_amd import _ffi

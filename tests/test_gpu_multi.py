@@ -47,6 +47,32 @@ def test_shares_on_one_device_match_oracle(world, n):
     assert pa.fr_ints_from_bytes(mg.converge_fr(0, 1000)) == [1000 if m else 0 for m in member]
 
 
+def test_shares_large_enough_to_order_the_cited_entries_by_workgroup():
+    """From a thousand rows per workgroup upwards a share asks for the other shares' entries grouped by the workgroup that
+    cites them, and the f64 sweep's workgroups follow the exact sweep's: the same scores."""
+    n = 1 << 20
+    frm, to, val = pa.synth_graph(3, n, 12 * n, seed=29, value_max=255)
+    member = np.ones(n, dtype=np.uint8)
+    member[::1013] = 0
+    iters = 6
+    rc, exp, nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000,
+                                                  n_threads=c_oracle.max_threads())
+    assert rc == 0
+    rc, _e, eld, _r, _n, _s = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000.0,
+                                                           n_threads=c_oracle.max_threads(), want_ld=True)
+    assert rc == 0
+    for world in (2, 3):
+        mg = pa.MultiGpuGraph(n, frm, to, value_u32=val, member=member, devices=[0] * world)
+        info = mg.info(0)
+        assert int(info.gather) == 1 and int(info.exact_sweep_blocks) % int(info.f64_sweep_blocks) == 0
+        assert int(info.rows_cap) // int(info.exact_sweep_blocks) >= 1024
+        assert sum(int(mg.info(r).nnz_local) for r in range(world)) == nnz
+        assert np.array_equal(mg.converge_fr(iters, 1000), exp)
+        o64, _ = mg.converge_f64(iters, 1000.0)
+        assert _rel_l1(o64, eld) <= 1e-9
+        mg.close()
+
+
 def test_damping_and_pretrust_over_shares():
     n = 20000
     frm, to, val, member = _graph(n, 77)

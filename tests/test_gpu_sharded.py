@@ -86,6 +86,32 @@ def test_sharded_converge_matches_oracle(world, chunks, local):
     assert ret["start"] == pa.fr_bytes_from_ints([1000 if m else 0 for m in member]).tobytes()
 
 
+def test_two_ranks_with_cited_entries_ordered_by_workgroup():
+    """Shares of half a million rows laid out from rank-local attestations: each rank asks the other for the entries it
+    cites in the order its workgroups want them (et_dplan_needs), and packs what the other asked for."""
+    import c_oracle
+    import protocol_amd as pa
+    n = 1 << 20
+    frm, to, val = pa.synth_graph(3, n, 12 * n, seed=31, value_max=255)
+    member = np.ones(n, dtype=np.uint8)
+    member[::997] = 0
+    iters = 5
+    rc, exp, nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000,
+                                                  n_threads=c_oracle.max_threads())
+    assert rc == 0
+    rc, _e64, eld, _r, _n, _s = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000.0,
+                                                             n_threads=c_oracle.max_threads(), want_ld=True)
+    assert rc == 0
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 27500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, (n, member, frm, to, val, iters, 1, True), ret), nprocs=2, join=True)
+    assert ret["nnz"] == nnz
+    assert ret["fr"] == exp.tobytes()
+    got = np.array(ret["f64"], dtype=np.longdouble)
+    assert float(np.abs(got - eld).sum() / np.abs(eld).sum()) <= 1e-9
+
+
 @pytest.mark.parametrize("world,full_vector", [(4, False), (8, False), (4, True)])
 def test_all_shares_in_one_process(world, full_vector):
     """The kernels on the layouts of 4 and 8 shares (what the 4- and 8-GPU runs execute), every share held by

@@ -25,7 +25,8 @@ import bench  # noqa: E402  (kernel_sources_sha)
 NAMES = {"k_step_f64_blocked": "k_step_f64_blocked<u8>", "k_step_fr_blocked": "k_step_fr_blocked", "k_step_fr_raw": "k_step_fr_raw"}
 
 
-def counters(root):
+def counters(root, names=None):
+    names = names or NAMES
     acc = defaultdict(lambda: [0.0, 0])
     for path in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
@@ -35,7 +36,7 @@ def counters(root):
                 acc[key][1] += 1
     out = defaultdict(dict)
     for (kernel, ctr), (tot, cnt) in acc.items():
-        for frag, name in NAMES.items():
+        for frag, name in names.items():
             if frag in kernel:
                 out[name][ctr] = tot / cnt
     return out
