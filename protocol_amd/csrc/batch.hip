@@ -680,9 +680,13 @@ struct DeviceBatch {
     int32_t* d_status = nullptr;
     uint64_t edges = 0;   // sum over sets of n_valid * (n_valid - 1): dense edge count of the reference
     bool owns = true;     // false: the arrays are carved out of the library's resident scratch array, nothing to free
+    // Small batches (one set through the set API): scores and status are written by the kernel straight into pinned host
+    // memory the GPU sees, so a converge is one launch and one wait, without copies (d_out / d_status then point into it).
+    void* h_map = nullptr;
     ~DeviceBatch() {
         if (!owns) return;
         if (device >= 0) (void)hipSetDevice(device);
+        if (h_map) { (void)hipHostFree(h_map); d_out = nullptr; d_status = nullptr; }
         void* p[] = {d_vals, d_member, d_dangling, d_scale, d_inw, d_pre, d_out, d_status, d_colsum};
         for (void* q : p) if (q) (void)hipFree(q);
     }
@@ -879,8 +883,17 @@ static int batch_create(uint32_t n_sets, uint32_t n, const uint8_t* member, cons
     BATCH_ALLOC(b.d_scale, rows * 32);
     BATCH_ALLOC(b.d_inw, (size_t)n_sets * 32);
     BATCH_ALLOC(b.d_pre, (size_t)n_sets * 4);
-    BATCH_ALLOC(b.d_out, rows * 32);
-    BATCH_ALLOC(b.d_status, (size_t)n_sets * 4);
+    const size_t out_bytes = (rows * 32 + 255) / 256 * 256;
+    if (!arena && out_bytes + (size_t)n_sets * 4 <= (256u << 10) && !getenv("ET_BATCH_NO_MAPPED_OUTPUT")) {
+        HIP_TRY_B(hipHostMalloc(&b.h_map, out_bytes + (size_t)n_sets * 4, hipHostMallocMapped));
+        void* dev = nullptr;
+        HIP_TRY_B(hipHostGetDevicePointer(&dev, b.h_map, 0));
+        b.d_out = static_cast<uint4*>(dev);
+        b.d_status = reinterpret_cast<int32_t*>(static_cast<char*>(dev) + out_bytes);
+    } else {
+        BATCH_ALLOC(b.d_out, rows * 32);
+        BATCH_ALLOC(b.d_status, (size_t)n_sets * 4);
+    }
     HIP_TRY_B(hipMemcpy(b.d_member, mem.data(), rows, hipMemcpyHostToDevice));
     HIP_TRY_B(hipMemcpy(b.d_dangling, dang.data(), rows, hipMemcpyHostToDevice));
     HIP_TRY_B(hipMemcpy(b.d_scale, scale.data(), rows * 32, hipMemcpyHostToDevice));
@@ -965,6 +978,13 @@ int et_batch_result_fr(et_batch* h, et_fr* out, int32_t* status, void* stream) {
     DeviceBatch& b = h->b;
     HIP_TRY_B(hipSetDevice(b.device));
     hipStream_t st = (hipStream_t)stream;
+    if (b.h_map) {                                         // the kernel wrote into host memory: wait for it, nothing to copy
+        HIP_TRY_B(hipStreamSynchronize(st));
+        const size_t out_bytes = ((size_t)b.n_sets * b.n * 32 + 255) / 256 * 256;
+        std::memcpy(out, b.h_map, (size_t)b.n_sets * b.n * 32);
+        if (status) std::memcpy(status, static_cast<const char*>(b.h_map) + out_bytes, (size_t)b.n_sets * 4);
+        return ET_OK;
+    }
     HIP_TRY_B(hipMemcpyAsync(out, b.d_out, (size_t)b.n_sets * b.n * 32, hipMemcpyDeviceToHost, st));
     if (status) HIP_TRY_B(hipMemcpyAsync(status, b.d_status, (size_t)b.n_sets * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY_B(hipStreamSynchronize(st));

@@ -31,6 +31,7 @@ int layout_common(uint32_t n, const uint8_t* member, bool values_are_u32, const 
                   const BuildOpts& opt, HostGraph& g, std::vector<uint32_t>& order, std::string& err) {
     auto is_member = [&](uint32_t i) { return member ? member[i] != 0 : true; };
     const uint32_t n_valid = g.n_valid;
+    g.value_max = values_are_u32 ? st.value_max : 0u;
     uint32_t n_dangling = 0;
     for (uint32_t i = 0; i < n; ++i) n_dangling += is_member(i) && dangling[i];
     // ---- 5. global row order ------------------------------------------------------------------
@@ -101,12 +102,13 @@ int layout_common(uint32_t n, const uint8_t* member, bool values_are_u32, const 
         const uint32_t win_hi = getenv("ET_FR_SWEEP_MAX_ROWS") ? (uint32_t)atoll(getenv("ET_FR_SWEEP_MAX_ROWS")) : 0xFFFFFFFFu;
         const uint32_t win_lo = getenv("ET_FR_SWEEP_MIN_ROWS") ? (uint32_t)atoll(getenv("ET_FR_SWEEP_MIN_ROWS")) : (1u << 14);
         const bool window = geo.rows_cap >= win_lo && geo.rows_cap <= win_hi;
-        bytes_only = bytes_only && st.value_max <= 255;
+        const bool wide = st.value_max > 255 && !getenv("ET_FR_SWEEP_BYTES_ONLY");   // 32-bit opinions: 40-byte rows
+        bytes_only = bytes_only && (st.value_max <= 255 || wide);
         if (bytes_only && window) {
             // whole rounds of 256 workgroups (one per CU), as few as the rows' LDS footprint allows: every round
             // pulls the whole vector through every L2 again
-            const bool compact = !getenv("ET_FR_WIDE_ROWS");          // measurement knob: the 64-byte rows
-            const uint32_t rb_max = compact ? FR_RB_MAX_COMPACT : FR_RB_MAX_WIDE;
+            const bool compact = wide || !getenv("ET_FR_WIDE_ROWS");  // measurement knob: the 64-byte rows
+            const uint32_t rb_max = wide ? FR_RB_MAX_U32 : (compact ? FR_RB_MAX_COMPACT : FR_RB_MAX_WIDE);
             uint32_t Bf = 256;
             while ((n_groups + Bf - 1) / Bf * BLOCK_GROUP > rb_max) Bf += 256;
             const uint32_t even_f = (n_groups + Bf - 1) / Bf;
@@ -114,14 +116,14 @@ int layout_common(uint32_t n, const uint8_t* member, bool values_are_u32, const 
             // levels the edges to about 2 %), so that its 1024 threads finish the rows in full passes
             geo.fr_blocks = Bf;
             geo.fr_rb = even_f * BLOCK_GROUP;
-            geo.fr_compact = compact ? 1u : 0u;
+            geo.fr_compact = wide ? 2u : (compact ? 1u : 0u);
             geo.fr_dblocks = dangling_blocks(Bf, geo.fr_rb / BLOCK_GROUP, geo.n_dangling_pad / BLOCK_GROUP / G);
             geo.nd_cap = std::max<uint32_t>(geo.nd_cap, (geo.fr_dblocks + 15) / 16 * 16);
         }
     }
     geo.n_chunks = 1;
     geo.chunk_rows = geo.rows_cap;
-    if (opt.n_chunks > 1 && geo.fr_blocks != 0) {
+    if (opt.n_chunks > 1 && geo.fr_blocks != 0 && geo.fr_compact != 2) {
         const uint32_t K = std::min<uint32_t>(opt.n_chunks, 8);
         const uint32_t cr = round_up((geo.rows_cap + K - 1) / K, 64);
         if ((uint64_t)(K - 1) * cr < geo.rows_cap) { geo.n_chunks = K; geo.chunk_rows = cr; }
@@ -1093,9 +1095,11 @@ int fill_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned T,
                 });
         // (c) the workgroups of the exact blocked sweep, when the geometry asks for them
         if (geo.fr_blocks) {
+            const bool wide = geo.fr_compact == 2;
             g.fb_col.resize(g.nnz_local);
             g.fb_row.resize(g.nnz_local);
-            g.fb_val.resize(g.nnz_local);
+            if (wide) g.fb_val_u32.resize(g.nnz_local);
+            else g.fb_val.resize(g.nnz_local);
             std::vector<uint64_t> fcur(g.fb_ptr.begin(), g.fb_ptr.end() - 1);
             const uint32_t BF = geo.fr_blocks;
             std::vector<uint32_t> owner_fr(BF, 0);
@@ -1107,7 +1111,8 @@ int fill_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned T,
                         const uint64_t q = fcur[dfr.block[grp]]++;
                         g.fb_col[q] = e.pf;
                         g.fb_row[q] = (uint16_t)(dfr.slot[grp] * BLOCK_GROUP + e.lr % BLOCK_GROUP);
-                        g.fb_val[q] = (uint8_t)src.value_u32(e.h);
+                        if (wide) g.fb_val_u32[q] = src.value_u32(e.h);
+                        else g.fb_val[q] = (uint8_t)src.value_u32(e.h);
                     });
         }
     }

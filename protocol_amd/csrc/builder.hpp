@@ -58,6 +58,7 @@ struct HostGraph {
     uint64_t nnz = 0;            // surviving edges of non-dangling peers, all segments
     uint64_t nnz_local = 0;      // ... whose destination row is in this segment
     bool values_are_u32 = true;
+    uint32_t value_max = 0;      // bit-or of the surviving integer opinions (how wide the edge records' opinions are)
     Geometry geo{};
     std::vector<uint32_t> pos_of_ext;   // n entries: position of each peer, 0xFFFFFFFF for empty slots
     std::vector<SliceDesc> slices;
@@ -78,7 +79,8 @@ struct HostGraph {
     std::vector<uint64_t> fb_ptr;
     std::vector<uint32_t> fb_grp, fb_col;
     std::vector<uint16_t> fb_row;
-    std::vector<uint8_t> fb_val;
+    std::vector<uint8_t> fb_val;        // byte opinions (geo.fr_compact != 2)
+    std::vector<uint32_t> fb_val_u32;   // 32-bit opinions (geo.fr_compact == 2)
     // chunked exchange: [workgroup][n_chunks + 1] absolute indices into the lists above, run q = edges whose source
     // lies in piece q (empty when n_chunks == 1)
     std::vector<uint64_t> bk_phase, fb_phase;

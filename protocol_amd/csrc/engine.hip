@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/eigentrust_hip.h"
@@ -191,7 +192,7 @@ template <typename VT, bool HAS_ALPHA, bool PACKED = false, bool PHASED = false>
 __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     static_assert(!(PACKED && PHASED), "runs of a chunked list do not start on a 64-edge boundary");
     constexpr bool RAW = sizeof(VT) != sizeof(double);
-    static_assert(!PACKED || sizeof(VT) == 1, "packed records carry byte opinions");
+    static_assert(!PACKED || RAW, "packed records carry integer opinions (one byte or four)");
     extern __shared__ double acc_l[];
     __shared__ double red[3][16];
     const int lane = threadIdx.x & 63;
@@ -720,7 +721,7 @@ struct StepArgsFrB {
     const uint32_t* grp;      // [fr_blocks][fr_rb / BLOCK_GROUP]
     const uint32_t* col;
     const uint16_t* row;
-    const uint8_t* val;
+    const void* val;          // opinion per edge: a byte, or 32 bits (WIDE)
     // packed records (see k_step_f64_blocked): accumulator row | (source position - base of the 64-edge chunk) << rec_shift
     uint32_t rec_shift;
     const uint32_t* rec;
@@ -729,7 +730,8 @@ struct StepArgsFrB {
     const uint4* x;
     uint4* y;
     uint4* own;
-    const uint4* scale288;    // inv(sum) * 2^288 per position
+    const uint4* scale288;    // inv(sum) * 2^288 per row
+    const uint4* scale576;    // inv(sum) * 2^576 per row (WIDE: the row is reduced to its plain score first)
     uint4* sum_part;          // [fr_blocks][2]
     uint32_t* chg_part;       // [fr_blocks]
     Geometry geo;
@@ -764,9 +766,16 @@ __global__ void k_scale_288(const uint4* __restrict__ scale576, uint4* __restric
 // !COMPACT: eight 64-bit column sums per row [8][RB] (limb times opinion byte, no carries until the row is folded).
 // PHASED: as for the f64 sweep.
 // PACKED: 5-byte edge records (one 32-bit record and the opinion byte) in place of 7 bytes (source, row, opinion).
-template <bool COMPACT, bool PHASED = false, bool PACKED = false>
+// WIDE: 32-bit opinions (the reference's opinion is any field element, native.rs:128; integers above a byte take this
+// form).  The product has 288 bits and a row's sum up to 2^310, so the top of a row is a 64-bit word (40 bytes per row,
+// [5][RB] words) and a row is reduced to its plain score before the product with its factor (208 instead of 144 limb
+// multiply-adds per row), as the row-per-lane kernel does.
+template <bool COMPACT, bool PHASED = false, bool PACKED = false, bool WIDE = false>
 __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     static_assert(!(PACKED && PHASED), "runs of a chunked list do not start on a 64-edge boundary");
+    static_assert(!WIDE || (COMPACT && !PHASED), "32-bit opinions: compact rows, one launch per iteration");
+    typedef typename std::conditional<WIDE, uint32_t, uint8_t>::type VT;
+    const VT* __restrict__ valp = static_cast<const VT*>(a.val);
     extern __shared__ unsigned long long colsum_l[];
     __shared__ uint32_t sh_d[9];
     __shared__ uint32_t sh_pd[17];
@@ -779,8 +788,9 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     const uint32_t stride = a.geo.seg_stride();
     const size_t my_base = a.geo.own_off;
     uint32_t* const top_l = reinterpret_cast<uint32_t*>(colsum_l + 4 * (size_t)RB);   // COMPACT: limb 8 of every row
+    unsigned long long* const top64_l = colsum_l + 4 * (size_t)RB;                    // WIDE: limbs 8 and 9
     const bool first_phase = !PHASED || a.phase == 0, last_phase = !PHASED || a.phase + 1 == a.n_phases;
-    const uint32_t lds_words = COMPACT ? 4 * RB + RB / 2 : 8 * RB;                     // RB is a multiple of 16
+    const uint32_t lds_words = WIDE ? 5 * RB : (COMPACT ? 4 * RB + RB / 2 : 8 * RB);   // RB is a multiple of 16
     for (uint32_t i = threadIdx.x; i < lds_words; i += 1024) colsum_l[i] = first_phase ? 0ull : a.acc_g[(size_t)b * lds_words + i];
     // partial-sum slots no workgroup writes: zero, whatever the caller's buffer held (see fr_zero_unused_tail)
     if (last_phase) fr_zero_unused_tail(a.y, a.geo, a.geo.fr_dblocks, 1024);
@@ -817,7 +827,8 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     auto carry_into = [&](uint32_t slot, uint32_t k) {
         for (; k < 4; ++k)
             if (atomicAdd(colsum_l + (size_t)k * RB + slot, 1ull) != ~0ull) return;
-        atomicAdd(top_l + slot, 1u);
+        if (WIDE) atomicAdd(top64_l + slot, 1ull);
+        else atomicAdd(top_l + slot, 1u);
     };
     auto add_edge = [&](uint32_t slot, uint32_t v, const uint4& lo, const uint4& hi) {
         unsigned long long* p = colsum_l + slot;
@@ -835,7 +846,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             t = (uint64_t)hi.z * v + (t >> 32);
             uint64_t w3 = (uint32_t)t;
             t = (uint64_t)hi.w * v + (t >> 32); w3 |= t << 32;
-            uint32_t w4 = (uint32_t)(t >> 32);
+            uint64_t w4 = t >> 32;                          // a byte opinion leaves 8 bits here, a 32-bit one 32
             const uint64_t o0 = atomicAdd(p + 0 * (size_t)RB, (unsigned long long)w0);
             const uint64_t o1 = atomicAdd(p + 1 * (size_t)RB, (unsigned long long)w1);
             const uint64_t o2 = atomicAdd(p + 2 * (size_t)RB, (unsigned long long)w2);
@@ -843,7 +854,8 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             // old + addend wrapped  <=>  old > ~addend
             const bool c1 = o0 > ~w0, c2 = o1 > ~w1, c3 = o2 > ~w2;
             w4 += o3 > ~w3 ? 1u : 0u;
-            if (w4) atomicAdd(top_l + slot, w4);
+            if (WIDE) atomicAdd(top64_l + slot, (unsigned long long)w4);
+            else if (w4) atomicAdd(top_l + slot, (uint32_t)w4);
             if (c1) carry_into(slot, 1);
             if (c2) carry_into(slot, 2);
             if (c3) carry_into(slot, 3);
@@ -865,7 +877,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
         uint32_t c[U], v[U], r[U];
         const uint32_t* __restrict__ cb = PACKED ? a.cbase + a.cptr[b] : nullptr;
         auto fetch = [&](uint64_t i, uint32_t& cc, uint32_t& vv, uint32_t& rr) {
-            vv = a.val[i];
+            vv = valp[i];
             if (PACKED) {
                 const uint32_t rc = a.rec[i];
                 cc = cb[(i - e0) >> 6] + (rc >> a.rec_shift);
@@ -910,7 +922,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             const bool in = i < e1;
             c[u] = v[u] = r[u] = 0u;                        // position / code 0 is a valid address
             if (in) {
-                v[u] = a.val[i];
+                v[u] = valp[i];
                 if (PACKED) {
                     const uint32_t rc = a.rec[i];
                     c[u] = a.cbase[a.cptr[b] + ((i - e0) >> 6)] + (rc >> a.rec_shift);
@@ -938,6 +950,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     }
 
     U256 dacc = u256_zero();                              // field sum of this thread's dangling rows' scores
+    U256 wsum = u256_zero();                              // WIDE: field sum of the plain scores of this thread's other rows
     Acc10 traw = acc10_zero();                            // integer sum of this thread's T
     uint32_t changed = 0;
     // eight 64-bit column sums, 32 bits apart, as ten limbs
@@ -949,8 +962,14 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
                 t[2 * j] = (uint32_t)w;
                 t[2 * j + 1] = (uint32_t)(w >> 32);
             }
-            t[8] = top_l[lr];
-            t[9] = 0;
+            if (WIDE) {
+                const unsigned long long w = top64_l[lr];
+                t[8] = (uint32_t)w;
+                t[9] = (uint32_t)(w >> 32);
+            } else {
+                t[8] = top_l[lr];
+                t[9] = 0;
+            }
             return;
         }
         uint64_t c = 0;
@@ -983,7 +1002,21 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
                 t[i] = (uint32_t)c;
                 c >>= 32;
             }
-            t[8] += (uint32_t)c;
+            if (WIDE) { c += t[8]; t[8] = (uint32_t)c; t[9] += (uint32_t)(c >> 32); }
+            else t[8] += (uint32_t)c;
+        }
+        if (WIDE) {
+            // ten limbs: the plain score first (one reduction), then its product with the factor
+            Acc full = acc_zero();
+#pragma unroll
+            for (int i = 0; i < 10; ++i) full.v[i] = t[i];
+            const U256 v = acc_redc288(full);
+            wsum = fr_add(wsum, v);
+            // changed: against the old exchanged entry, as below (so the last step forms the scaled entry too)
+            const U256 xs = fr_mul_redc288(v, u256_load(a.scale576 + 2 * (size_t)row));
+            changed += u256_eq(xs, u256_load(a.x + 2 * (my_base + row))) ? 0u : 1u;
+            u256_store(a.y + 2 * (my_base + row), a.final_step ? v : xs);
+            continue;
         }
         {
             uint64_t c = 0;
@@ -1027,7 +1060,13 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
         }
     }
     // per wavefront: integer sum of the T, field sum of the dangling rows' scores (leading workgroups only), count
-    acc10_group_sum(traw, 64);
+    if (WIDE) {
+        wsum = fr_wave_sum(wsum);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) traw.v[i] = wsum.v[i];
+    } else {
+        acc10_group_sum(traw, 64);
+    }
     if (b < a.geo.fr_dblocks) dacc = fr_wave_sum(dacc);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) changed += __shfl_xor(changed, off, 64);
@@ -1049,13 +1088,21 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             d = u256_load(red_l + 2 * lane);
             ch = red_c[lane];
         }
-        acc10_group_sum(r10, 16);
+        U256 others;                                      // score sum of the rows with opinions
+        if (WIDE) {                                       // sixteen field sums (the lanes beyond hold zero)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) others.v[i] = r10.v[i];
+            others = fr_wave_sum(others);
+        } else {
+            acc10_group_sum(r10, 16);
+            others = acc_redc288(acc_from_acc10(r10));    // the reduced integer sum of the T
+        }
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) ch += __shfl_xor(ch, off, 64);
         if (b < a.geo.fr_dblocks) d = fr_wave_sum(d);
         if (lane == 0) {
-            // score sum of the workgroup's rows: the dangling rows' plain scores plus the reduced integer sum
-            u256_store(a.sum_part + 2 * (size_t)b, fr_add(d, acc_redc288(acc_from_acc10(r10))));
+            // score sum of the workgroup's rows: the dangling rows' plain scores plus the others'
+            u256_store(a.sum_part + 2 * (size_t)b, fr_add(d, others));
             a.chg_part[b] = ch;
             if (b < a.geo.fr_dblocks) u256_store(a.y + 2 * (my_base + a.geo.rows_cap + b), d);   // partial sum slot b
         }
@@ -1344,9 +1391,16 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     uint4* d_valfr = nullptr;
     auto free_tmp = [&]() { if (d_valfr) (void)hipFree(d_valfr); d_valfr = nullptr; };
     if (g->raw) {
-        uint32_t vmax = 0;
+        // how wide the edge records' opinions are: from the plan's figure over ALL surviving opinions (the per-row
+        // stream below is empty where both variants run the blocked sweep)
+        uint32_t vmax = h.value_max;
         for (uint32_t v : h.val_u32) vmax = std::max(vmax, v);
+        for (uint32_t v : h.bk_val_u32) vmax = std::max(vmax, v);
         g->val_bytes = vmax <= 255 ? 1 : 4;
+        if ((h.geo.fr_compact == 2) != (g->val_bytes == 4) && h.geo.fr_blocks != 0) {
+            set_error("internal: the exact sweep's rows do not match the width of the opinions");
+            return ET_E_INVALID_ARG;
+        }
     }
     // narrows 32-bit opinions to bytes when they fit
     auto upload_values = [&](void** dst, const std::vector<uint32_t>& v) -> int {
@@ -1373,7 +1427,7 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
         HIP_TRY(hipMemcpy(d_scale_fr_all, h.scale_fr.data(), full_len * 32, hipMemcpyHostToDevice));
     }
     const unsigned nb = (unsigned)((slots + 255) / 256);
-    const bool can_pack = g->raw && g->val_bytes == 1 && vec_len <= 0xFFFFFFFFull && h.geo.n_chunks == 1;
+    const bool can_pack = g->raw && vec_len <= 0xFFFFFFFFull && h.geo.n_chunks == 1;
     if (g->variants & ET_VARIANT_F64) {
         g->n_f64_parts = h.geo.f64_blocks;
         const size_t ne = h.bk_col.size();
@@ -1442,8 +1496,9 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
             if ((rc = dev_upload(&g->d_fb_phase, h.fb_phase, tot)) || (rc = dev_alloc(&g->d_fr_acc, (size_t)h.geo.fr_blocks * words, tot))) return rc;
         }
         if (g->fr_blocked) {
-            if ((rc = dev_upload(&g->d_fb_ptr, h.fb_ptr, tot)) || (rc = dev_upload(&g->d_fb_grp, h.fb_grp, tot)) ||
-                (rc = dev_upload(&g->d_fb_val, h.fb_val, tot))) return rc;
+            if ((rc = dev_upload(&g->d_fb_ptr, h.fb_ptr, tot)) || (rc = dev_upload(&g->d_fb_grp, h.fb_grp, tot))) return rc;
+            if (h.geo.fr_compact == 2) { uint32_t* p = nullptr; if ((rc = dev_upload(&p, h.fb_val_u32, tot))) return rc; g->d_fb_val = p; }
+            else { uint8_t* p = nullptr; if ((rc = dev_upload(&p, h.fb_val, tot))) return rc; g->d_fb_val = p; }
             if (can_pack && h.geo.fr_compact && !getenv("ET_FR_UNPACKED")) {
                 std::vector<uint64_t> cptr;
                 std::vector<uint32_t> cbase, rec;
@@ -1455,7 +1510,8 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
                 }
             }
             if (!g->fr_packed && ((rc = dev_upload(&g->d_fb_col, h.fb_col, tot)) || (rc = dev_upload(&g->d_fb_row, h.fb_row, tot)))) return rc;
-            const void* sweeps[] = {(const void*)k_step_fr_blocked<true, false, true>,
+            const void* sweeps[] = {(const void*)k_step_fr_blocked<true, false, true, true>, (const void*)k_step_fr_blocked<true, false, false, true>,
+                                    (const void*)k_step_fr_blocked<true, false, true>,
                                     (const void*)k_step_fr_blocked<true, false>, (const void*)k_step_fr_blocked<false, false>,
                                     (const void*)k_step_fr_blocked<true, true>, (const void*)k_step_fr_blocked<false, true>};
             for (const void* f : sweeps) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
@@ -1497,6 +1553,7 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     {
         const int lds_max = 160 * 1024 - 1024;
         const void* fns[] = {(const void*)k_step_f64_blocked<uint8_t, false, true>, (const void*)k_step_f64_blocked<uint8_t, true, true>,
+                             (const void*)k_step_f64_blocked<uint32_t, false, true>, (const void*)k_step_f64_blocked<uint32_t, true, true>,
                              (const void*)k_step_f64_blocked<uint8_t, false, false, true>, (const void*)k_step_f64_blocked<uint8_t, true, false, true>,
                              (const void*)k_step_f64_blocked<uint8_t, false>, (const void*)k_step_f64_blocked<uint8_t, true>,
                              (const void*)k_step_f64_blocked<uint32_t, false>, (const void*)k_step_f64_blocked<uint32_t, true>,
@@ -1562,7 +1619,8 @@ int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double
             launch_f64<uint8_t, false, true>(a, geo.f64_blocks, lds, st);
         }
         else if (!raw) launch_f64<double>(a, geo.f64_blocks, lds, st);
-        else if (packed) launch_f64<uint8_t, true>(a, geo.f64_blocks, lds, st);
+        else if (packed && val_bytes == 1) launch_f64<uint8_t, true>(a, geo.f64_blocks, lds, st);
+        else if (packed) launch_f64<uint32_t, true>(a, geo.f64_blocks, lds, st);
         else if (val_bytes == 1) launch_f64<uint8_t>(a, geo.f64_blocks, lds, st);
         else launch_f64<uint32_t>(a, geo.f64_blocks, lds, st);
     }
@@ -1577,7 +1635,7 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
         const size_t ringb = (size_t)(iteration % STATS_RING) * n_fr_parts;
         fb.ptr = d_fb_ptr; fb.grp = d_fb_grp; fb.col = d_fb_col; fb.row = d_fb_row; fb.val = d_fb_val; fb.x = x; fb.y = y;
         fb.rec = d_fb_rec; fb.cbase = d_fb_cbase; fb.cptr = d_fb_cptr; fb.rec_shift = fr_rec_shift;
-        fb.own = own_fr; fb.scale288 = d_fb_scale; fb.sum_part = d_frsum_part + 2 * ringb; fb.chg_part = d_chg_part + ringb;
+        fb.own = own_fr; fb.scale288 = d_fb_scale; fb.scale576 = d_scale_fr; fb.sum_part = d_frsum_part + 2 * ringb; fb.chg_part = d_chg_part + ringb;
         fb.geo = geo; fb.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u; fb.inv_nm1_w = to_u256(inv_nm1_w);
         fb.inv_nm1_w576 = to_u256((Fr::from_raw(inv_nm1_w) * Fr::one().pow2k(288)).to_raw());
         fb.phase_ptr = d_fb_phase; fb.acc_g = d_fr_acc; fb.n_phases = geo.n_chunks;
@@ -1586,12 +1644,14 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
         for (uint32_t q = phase < 0 ? 0u : (uint32_t)phase; q < (phase < 0 ? geo.n_chunks : (uint32_t)phase + 1); ++q) {
             fb.phase = q;
             const dim3 grid(geo.fr_blocks), wg(1024);
-            const size_t lds = (size_t)geo.fr_rb * (geo.fr_compact ? 36 : 64);
+            const size_t lds = (size_t)geo.fr_rb * (geo.fr_compact == 2 ? 40 : (geo.fr_compact ? 36 : 64));
             if (geo.n_chunks > 1) {
                 if (geo.fr_compact) hipLaunchKernelGGL((k_step_fr_blocked<true, true>), grid, wg, lds, st, fb);
                 else hipLaunchKernelGGL((k_step_fr_blocked<false, true>), grid, wg, lds, st, fb);
             } else {
-                if (fr_packed) hipLaunchKernelGGL((k_step_fr_blocked<true, false, true>), grid, wg, lds, st, fb);
+                if (geo.fr_compact == 2 && fr_packed) hipLaunchKernelGGL((k_step_fr_blocked<true, false, true, true>), grid, wg, lds, st, fb);
+                else if (geo.fr_compact == 2) hipLaunchKernelGGL((k_step_fr_blocked<true, false, false, true>), grid, wg, lds, st, fb);
+                else if (fr_packed) hipLaunchKernelGGL((k_step_fr_blocked<true, false, true>), grid, wg, lds, st, fb);
                 else if (geo.fr_compact) hipLaunchKernelGGL((k_step_fr_blocked<true, false>), grid, wg, lds, st, fb);
                 else hipLaunchKernelGGL((k_step_fr_blocked<false, false>), grid, wg, lds, st, fb);
             }

@@ -77,7 +77,7 @@ struct DeviceGraph {
     uint32_t* d_fb_grp = nullptr;
     uint32_t* d_fb_col = nullptr;
     uint16_t* d_fb_row = nullptr;
-    uint8_t* d_fb_val = nullptr;
+    void* d_fb_val = nullptr;         // a byte per edge, or 32 bits (geo.fr_compact == 2)
     uint4* d_fb_scale = nullptr;      // inv(sum) * 2^288 per position
     // chunked exchange (geo.n_chunks > 1): runs of the workgroups' lists per piece, partial sums between an iteration's launches
     uint64_t* d_bk_phase = nullptr;

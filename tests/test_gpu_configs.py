@@ -36,6 +36,34 @@ def test_64k_peers_1m_attestations_full_result():
     assert rel_l1(o64, eld) <= F64_TOL
 
 
+def test_1m_peers_16m_attestations_with_32_bit_opinions():
+    """The benchmark graph with opinions drawn from 1..2^32-1 (the stress set for opinions that do not fit a byte): whole
+    result on one GPU, and the same graph cut into two shares with gather vectors."""
+    n = 1 << 20
+    frm, to, val = pa.synth_graph(3, n, 1 << 24, seed=42, value_max=0xFFFFFFFF)
+    assert int(val.max()) > 0xF0000000
+    member = np.ones(n, dtype=np.uint8)
+    iters = 20
+    rc, exp, nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000,
+                                                  n_threads=c_oracle.max_threads())
+    assert rc == 0
+    rc, _e, eld, _r, _, _ = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=iters, initial=1000.0,
+                                                         n_threads=c_oracle.max_threads(), want_ld=True)
+    assert rc == 0
+    g = pa.Graph(n, frm, to, value_u32=val, member=member)
+    assert int(g.info.nnz) == nnz and int(g.info.exact_sweep_blocks) == 512     # 40-byte rows: two rounds of 256 workgroups
+    assert np.array_equal(g.converge_fr(iters, 1000), exp)
+    o64, _ = g.converge_f64(iters, 1000.0)
+    assert rel_l1(o64, eld) <= F64_TOL
+    g.close()
+    mg = pa.MultiGpuGraph(n, frm, to, value_u32=val, member=member, devices=[0, 0])
+    assert int(mg.info(0).gather) == 1 and int(mg.info(1).exact_sweep_blocks) != 0
+    assert np.array_equal(mg.converge_fr(iters, 1000), exp)
+    o64, _ = mg.converge_f64(iters, 1000.0)
+    assert rel_l1(o64, eld) <= F64_TOL
+    mg.close()
+
+
 @pytest.fixture(scope="module")
 def big_graph():
     n = 1 << 24

@@ -241,17 +241,43 @@ def test_both_exact_kernels_above_half_a_million_rows(row_per_lane, monkeypatch)
                                                       n_threads=c_oracle.max_threads())[1])
 
 
-def test_exact_sweep_is_not_chosen_outside_its_window():
-    # opinions above 255 at the same size keep the row-per-lane kernel
+def test_exact_sweep_with_32_bit_opinions(monkeypatch):
+    """Opinions above a byte (the reference's opinion is any field element, native.rs:128): the exact variant runs the blocked
+    sweep with ten-limb rows, the f64 sweep 8-byte packed records.  Hubs rated by thousands with the largest opinion
+    stress the carries of a row's 320-bit sum."""
     rng = np.random.default_rng(78)
     n = 600000
-    member, frm, to, val = random_graph(rng, n, 3, 0.0, 0.02, 70000)
+    member, frm, to, val = random_graph(rng, n, 3, 0.0, 0.02, 2**32 - 1, True)
+    big = np.flatnonzero(to < 3)
+    val[big[: len(big) // 2]] = 0xFFFFFFFF
+    rc, exp, nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=5, initial=1000,
+                                                  n_threads=c_oracle.max_threads())
+    assert rc == 0
+    rc, _e, eld, _r, _n, _s = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=5, initial=1000.0,
+                                                           n_threads=c_oracle.max_threads(), want_ld=True)
+    assert rc == 0
+    g = pa.Graph(n, frm, to, value_u32=val, member=member)
+    assert int(g.info.exact_sweep_blocks) != 0 and int(g.info.nnz) == nnz
+    assert np.array_equal(g.converge_fr(5, 1000), exp)
+    assert np.array_equal(g.converge_fr(1, 1000),
+                          c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=1, initial=1000,
+                                                      n_threads=c_oracle.max_threads())[1])
+    o64, _ = g.converge_f64(5, 1000.0)
+    assert rel_l1(o64, eld) <= F64_TOL
+    g.close()
+    # unpacked records (source, slot and opinion apart) run the same arithmetic
+    monkeypatch.setenv("ET_FR_UNPACKED", "1")
+    monkeypatch.setenv("ET_F64_UNPACKED", "1")
+    g = pa.Graph(n, frm, to, value_u32=val, member=member)
+    assert int(g.info.exact_sweep_blocks) != 0
+    assert np.array_equal(g.converge_fr(5, 1000), exp)
+    assert rel_l1(g.converge_f64(5, 1000.0)[0], eld) <= F64_TOL
+    g.close()
+    # the row-per-lane kernel on the same graph (what 32-bit opinions ran before the sweep took them)
+    monkeypatch.setenv("ET_FR_SWEEP_BYTES_ONLY", "1")
     g = pa.Graph(n, frm, to, value_u32=val, member=member, variants=1)
     assert int(g.info.exact_sweep_blocks) == 0
-    rc, exp, _nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=3, initial=1000,
-                                                   n_threads=c_oracle.max_threads())
-    assert rc == 0
-    assert np.array_equal(g.converge_fr(3, 1000), exp)
+    assert np.array_equal(g.converge_fr(5, 1000), exp)
 
 
 def test_full_size_benchmark_graph_parity():
