@@ -87,6 +87,7 @@ pub struct et_build_opts {
     pub xcd_cost: [u32; 8],
 }
 pub const ET_BUILD_FULL_VECTOR: u32 = 1;
+pub const ET_BUILD_REUSED: u32 = 2;
 
 #[repr(C)]
 #[derive(Clone, Copy, Default)]

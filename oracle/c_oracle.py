@@ -11,6 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libet_oracle.so")
 _lib = None
+_max_threads = 1
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
@@ -31,6 +32,8 @@ def lib():
         _lib.oracle_dense_converge_fr.restype = C.c_int
         _lib.oracle_sparse_converge_fr.restype = C.c_int
         _lib.oracle_sparse_converge_f64.restype = C.c_int
+        global _max_threads
+        _max_threads = int(_lib.oracle_max_threads())     # before any call narrows the OpenMP team (a call with n_threads sets it)
     return _lib
 
 
@@ -132,4 +135,7 @@ def sparse_converge_f64(n, member, frm, to, value_u32=None, value_fr=None, num_i
 
 
 def max_threads():
-    return lib().oracle_max_threads()
+    """Threads the checker may use on this host: what OpenMP offered when the library was loaded (a converge called with
+    n_threads = 1 narrows the team for later calls, so asking again would answer 1)."""
+    lib()
+    return _max_threads

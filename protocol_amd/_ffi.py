@@ -49,6 +49,7 @@ class EtBuildOpts(C.Structure):
 
 
 ET_BUILD_FULL_VECTOR = 1
+ET_BUILD_REUSED = 2
 
 
 class EtGraphInfo(C.Structure):

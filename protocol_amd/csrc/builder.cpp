@@ -546,7 +546,8 @@ int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& pc, std:
     if ((rc = layout_common(in.n, in.member, g.values_are_u32, pc.dangling, st, opt, g, pc.order, err))) return rc;
     {
         const char* e = getenv("ET_AFFINITY");
-        if (opt.n_seg == 1 && g.geo.n_chunks == 1 && g.geo.fr_blocks != 0 && g.geo.fr_blocks % g.geo.f64_blocks == 0 && !(e && atoi(e) == 0))
+        const bool wanted = e ? atoi(e) != 0 : opt.reused;      // pays off after thousands of converges of the same graph
+        if (opt.n_seg == 1 && g.geo.n_chunks == 1 && g.geo.fr_blocks != 0 && g.geo.fr_blocks % g.geo.f64_blocks == 0 && wanted)
             cluster_cold_sources(pc, st, opt);
     }
     // ---- 6. per-position source factors ------------------------------------------------------

@@ -45,6 +45,7 @@ struct BuildOpts {
     // instead of ascending.  The shares that pack for this one must then be told the order (HostGraph::need): set by the
     // callers that deliver it (the one-thread driver, the rank-local plan).
     bool cluster_cited = false;
+    bool reused = false;         // one share: worth the planner's time to place peers beside the peers their workgroup gathers
     bool full_vector = false;    // several shares: keep every share's whole segment in the vectors (all-gather exchange) instead of the cited entries only
     // Relative time a workgroup on XCD x (workgroup b runs on XCD b mod 8) needs per edge of a blocked sweep, in 1/1024
     // (1024 = the same everywhere): the deal levels edges x cost instead of edges.  Measured per device by

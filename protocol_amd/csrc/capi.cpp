@@ -84,6 +84,7 @@ static void read_opts(const et_build_opts* opts, BuildOpts& bo, int& variants, i
     device = opts->device;
     if (opts->n_chunks) bo.n_chunks = opts->n_chunks;
     bo.full_vector = (opts->flags & ET_BUILD_FULL_VECTOR) != 0;
+    bo.reused = (opts->flags & ET_BUILD_REUSED) != 0;
 }
 
 // Tuning knobs for experiments (not part of the ABI): ET_TARGET_WORK, ET_LONG_ROW, ET_F64_BLOCKS, ET_HOT_PREFIX.

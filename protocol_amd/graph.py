@@ -160,7 +160,8 @@ class Graph:
 
     def __init__(self, n, frm, to, value_u32=None, value_fr=None, member=None, n_seg=1, seg=0,
                  variants=_ffi.ET_VARIANT_FR | _ffi.ET_VARIANT_F64, device=-1, long_row=0,
-                 target_work=0, n_chunks=1, full_vector=False):
+                 target_work=0, n_chunks=1, full_vector=False, reused=False):
+        # reused: the graph will be converged thousands of times before it changes (ET_BUILD_REUSED): a slower plan, faster steps
         frm = np.ascontiguousarray(frm, dtype=np.uint32)
         to = np.ascontiguousarray(to, dtype=np.uint32)
         if len(frm) != len(to):
@@ -174,7 +175,7 @@ class Graph:
             if len(member) != n:
                 raise ValueError("member flags must have n entries")
         opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, variants, device, n_chunks,
-                                _ffi.ET_BUILD_FULL_VECTOR if full_vector else 0)
+                                (_ffi.ET_BUILD_FULL_VECTOR if full_vector else 0) | (_ffi.ET_BUILD_REUSED if reused else 0))
         h = C.c_void_p()
         check(lib().et_graph_build(n, _ptr(member), len(frm), _ptr(frm), _ptr(to), _ptr(value_u32),
                                    _ptr(value_fr), C.byref(opts), C.byref(h)))
@@ -366,7 +367,7 @@ class Plan:
     Arrays are copied into numpy so they outlive the native object."""
 
     def __init__(self, n, frm, to, value_u32=None, value_fr=None, member=None, n_seg=1, seg=0,
-                 long_row=0, target_work=0, full_vector=False):
+                 long_row=0, target_work=0, full_vector=False, reused=False):
         frm = np.ascontiguousarray(frm, dtype=np.uint32)
         to = np.ascontiguousarray(to, dtype=np.uint32)
         if value_u32 is not None:
@@ -375,7 +376,8 @@ class Plan:
             value_fr = np.ascontiguousarray(value_fr, dtype=np.uint8)
         if member is not None:
             member = np.ascontiguousarray(member, dtype=np.uint8)
-        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, 0, -1, 1, _ffi.ET_BUILD_FULL_VECTOR if full_vector else 0)
+        opts = _ffi.EtBuildOpts(n_seg, seg, long_row, target_work, 0, -1, 1,
+                                (_ffi.ET_BUILD_FULL_VECTOR if full_vector else 0) | (_ffi.ET_BUILD_REUSED if reused else 0))
         h = C.c_void_p()
         check(lib().et_plan_build(n, _ptr(member), len(frm), _ptr(frm), _ptr(to), _ptr(value_u32),
                                   _ptr(value_fr), C.byref(opts), C.byref(h)))

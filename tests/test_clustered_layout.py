@@ -43,6 +43,17 @@ def test_clustered_positions_are_a_permutation_with_level_workgroups_and_fewer_l
     assert np.array_equal(plain.scale_f64[pa_[members]], clustered.scale_f64[pb[members]])
 
 
+def test_clustering_is_asked_for_by_the_caller_who_reuses_the_graph(graph, monkeypatch):
+    """Without a word from the caller a single share keeps the degree order (the plan is a third faster); ET_BUILD_REUSED
+    asks for the clustered positions; the environment overrides both."""
+    frm, to, val = graph
+    monkeypatch.delenv("ET_AFFINITY", raising=False)
+    assert pa.Plan(N, frm, to, value_u32=val).sweep["f64"]["clustered"] == 0
+    assert pa.Plan(N, frm, to, value_u32=val, reused=True).sweep["f64"]["clustered"] == 1
+    monkeypatch.setenv("ET_AFFINITY", "0")
+    assert pa.Plan(N, frm, to, value_u32=val, reused=True).sweep["f64"]["clustered"] == 0
+
+
 def test_small_graphs_and_several_shares_keep_the_degree_order(monkeypatch):
     frm, to, val = pa.synth_graph(3, 1 << 15, 1 << 19, seed=3, value_max=255)
     monkeypatch.setenv("ET_AFFINITY", "1")
