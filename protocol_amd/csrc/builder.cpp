@@ -57,9 +57,9 @@ int layout_common(uint32_t n, const uint8_t* member, bool values_are_u32, const 
         auto b = order.begin();
         if (h1 < n_active) std::nth_element(b, b + h1, b + n_active, by_out);
         std::sort(b, b + h1, by_deg);
-        std::sort(b + h1, b + n_active, by_deg);
+        parallel_sort(b + h1, b + n_active, by_deg, host_threads());
     }
-    std::sort(order.begin() + n_active, order.end(), by_deg);
+    parallel_sort(order.begin() + n_active, order.end(), by_deg, host_threads());
 
     const uint32_t G = opt.n_seg;
     Geometry geo{};
@@ -196,67 +196,99 @@ int filter_edges(const BuildInput& in, PlanCommon& pc, RowSums& sums, PeerStats&
     }
 
     // ---- 1. filter (native.rs:248-260) and group by attester --------------------------------
+    // The passes over the attestation list run on the host threads.  Lists that arrive grouped by attester (ascending
+    // `from`: what a caller that walks its attesters produces) are filtered in place, chunk by chunk; any other order takes
+    // the counting sort below on one thread (the order inside an attester's group must stay the list's: a later attestation
+    // for the same pair replaces an earlier one).
     const uint64_t ne = in.n_edges;
+    const unsigned T = host_threads();
     std::vector<uint64_t>& out_ptr = pc.out_ptr;
     out_ptr.assign((size_t)n + 1, 0);
-    for (uint64_t e = 0; e < ne; ++e) {
-        uint32_t f = in.from[e], t = in.to[e];
-        if (f >= n || t >= n) {
-            err = "edge endpoint out of range";
-            return ET_E_OUT_OF_RANGE;
+    auto keeps = [&](uint64_t e) { const uint32_t f = in.from[e], t = in.to[e]; return f != t && is_member(f) && is_member(t); };
+    std::vector<uint64_t> chunk_kept(T + 1, 0);
+    std::vector<uint8_t> chunk_bad(T, 0), chunk_unsorted(T, 0);
+    run_threads(T, [&](unsigned t) {
+        uint64_t c = 0;
+        const uint64_t e0 = ne * t / T, e1 = ne * (t + 1) / T;
+        for (uint64_t e = e0; e < e1; ++e) {
+            const uint32_t f = in.from[e], to = in.to[e];
+            if (f >= n || to >= n) { chunk_bad[t] = 1; return; }
+            if (e > 0 && in.from[e - 1] > f) chunk_unsorted[t] = 1;
+            if (f == to || !is_member(f) || !is_member(to)) continue;
+            ++c;
+            __atomic_fetch_add(&out_ptr[f + 1], 1, __ATOMIC_RELAXED);
         }
-        if (f == t || !is_member(f) || !is_member(t)) continue;
-        out_ptr[f + 1]++;
-    }
+        chunk_kept[t + 1] = c;
+    });
+    for (unsigned t = 0; t < T; ++t) if (chunk_bad[t]) { err = "edge endpoint out of range"; return ET_E_OUT_OF_RANGE; }
+    bool grouped = true;
+    for (unsigned t = 0; t < T; ++t) grouped = grouped && !chunk_unsorted[t];
     for (uint32_t i = 0; i < n; ++i) out_ptr[i + 1] += out_ptr[i];
     const uint64_t m0 = out_ptr[n];
     // kept[k] = original edge index, grouped by attester, original order inside a group
     std::vector<uint64_t>& kept = pc.kept;
     kept.assign(m0, 0);
-    {
+    if (grouped) {
+        for (unsigned t = 0; t < T; ++t) chunk_kept[t + 1] += chunk_kept[t];
+        run_threads(T, [&](unsigned t) {
+            uint64_t k = chunk_kept[t];
+            for (uint64_t e = ne * t / T; e < ne * (t + 1) / T; ++e) if (keeps(e)) kept[k++] = e;
+        });
+    } else {
         std::vector<uint64_t> cur(out_ptr.begin(), out_ptr.end() - 1);
-        for (uint64_t e = 0; e < ne; ++e) {
-            uint32_t f = in.from[e], t = in.to[e];
-            if (f == t || !is_member(f) || !is_member(t)) continue;
-            kept[cur[f]++] = e;
-        }
+        for (uint64_t e = 0; e < ne; ++e) if (keeps(e)) kept[cur[in.from[e]]++] = e;
     }
+    // every later pass walks attesters: T ranges of them with about equal numbers of attestations
+    std::vector<uint32_t> cut(T + 1, n);
+    cut[0] = 0;
+    for (unsigned t = 1; t < T; ++t) cut[t] = (uint32_t)(std::lower_bound(out_ptr.begin(), out_ptr.end(), m0 * t / T) - out_ptr.begin());
+    for (unsigned t = 1; t <= T; ++t) cut[t] = std::min<uint32_t>(n, std::max(cut[t], cut[t - 1]));
+    cut[T] = n;
     // ---- 2. inside each attester: order by rated peer, last write wins (lib.rs:415) ---------
     std::vector<uint8_t>& drop = pc.drop;
     drop.assign(m0, 0);
-    for (uint32_t f = 0; f < n; ++f) {
-        uint64_t b = out_ptr[f], e = out_ptr[f + 1];
-        if (e - b < 2) continue;
-        bool sorted_unique = true;
-        for (uint64_t k = b + 1; k < e; ++k)
-            if (in.to[kept[k - 1]] >= in.to[kept[k]]) { sorted_unique = false; break; }
-        if (sorted_unique) continue;
-        std::stable_sort(kept.begin() + b, kept.begin() + e, [&](uint64_t x, uint64_t y) { return in.to[x] < in.to[y]; });
-        for (uint64_t k = b; k + 1 < e; ++k)
-            if (in.to[kept[k]] == in.to[kept[k + 1]]) drop[k] = 1;  // an equal later one follows
-    }
+    run_threads(T, [&](unsigned t) {
+        for (uint32_t f = cut[t]; f < cut[t + 1]; ++f) {
+            uint64_t b = out_ptr[f], e = out_ptr[f + 1];
+            if (e - b < 2) continue;
+            bool sorted_unique = true;
+            for (uint64_t k = b + 1; k < e; ++k)
+                if (in.to[kept[k - 1]] >= in.to[kept[k]]) { sorted_unique = false; break; }
+            if (sorted_unique) continue;
+            std::stable_sort(kept.begin() + b, kept.begin() + e, [&](uint64_t x, uint64_t y) { return in.to[x] < in.to[y]; });
+            for (uint64_t k = b; k + 1 < e; ++k)
+                if (in.to[kept[k]] == in.to[kept[k + 1]]) drop[k] = 1;  // an equal later one follows
+        }
+    });
     // ---- 3. row sums: in the field (dangling test, native.rs:263-264) and as integers -------
     std::vector<Fr>& sum_fr = sums.fr;
     std::vector<uint64_t>& sum_u64 = sums.u64;
     std::vector<long double>& sum_ld = sums.ld;
     if (g.values_are_u32) sum_u64.assign(n, 0);
     else { sum_fr.assign(n, Fr::zero()); sum_ld.assign(n, 0.0L); }
-    uint32_t vmax = 0;                                   // largest surviving integer opinion
-    for (uint32_t f = 0; f < n; ++f) {
-        for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
-            if (drop[k]) continue;
-            uint64_t e = kept[k];
-            if (g.values_are_u32) { sum_u64[f] += in.val_u32[e]; vmax = std::max(vmax, in.val_u32[e]); }
-            else {
-                const FrRaw& v = in.val_fr[e];
-                if (!fr_raw_is_canonical(v.l)) {
-                    err = "opinion value is not a canonical field element";
-                    return ET_E_NONCANONICAL_FR;
+    std::vector<uint32_t> vmax_t(T, 0);                 // largest surviving integer opinion, per thread
+    std::vector<uint8_t> noncanonical(T, 0);
+    run_threads(T, [&](unsigned t) {
+        uint32_t vmax = 0;
+        for (uint32_t f = cut[t]; f < cut[t + 1]; ++f) {
+            for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
+                if (drop[k]) continue;
+                uint64_t e = kept[k];
+                if (g.values_are_u32) { sum_u64[f] += in.val_u32[e]; vmax = std::max(vmax, in.val_u32[e]); }
+                else {
+                    const FrRaw& v = in.val_fr[e];
+                    if (!fr_raw_is_canonical(v.l)) { noncanonical[t] = 1; return; }
+                    sum_fr[f] += Fr::from_raw(v);
+                    sum_ld[f] += (long double)v.l[0] + 18446744073709551616.0L * ((long double)v.l[1] + 18446744073709551616.0L * ((long double)v.l[2] + 18446744073709551616.0L * (long double)v.l[3]));
                 }
-                sum_fr[f] += Fr::from_raw(v);
-                sum_ld[f] += (long double)v.l[0] + 18446744073709551616.0L * ((long double)v.l[1] + 18446744073709551616.0L * ((long double)v.l[2] + 18446744073709551616.0L * (long double)v.l[3]));
             }
         }
+        vmax_t[t] = vmax;
+    });
+    uint32_t vmax = 0;
+    for (unsigned t = 0; t < T; ++t) {
+        if (noncanonical[t]) { err = "opinion value is not a canonical field element"; return ET_E_NONCANONICAL_FR; }
+        vmax = std::max(vmax, vmax_t[t]);
     }
     std::vector<uint8_t>& dangling = pc.dangling;
     dangling.assign(n, 0);
@@ -269,16 +301,22 @@ int filter_edges(const BuildInput& in, PlanCommon& pc, RowSums& sums, PeerStats&
     st.in_deg.assign(n, 0);
     st.out_deg.assign(n, 0);
     st.value_max = vmax;
-    uint64_t nnz = 0;
-    for (uint32_t f = 0; f < n; ++f) {
-        if (dangling[f]) continue;
-        for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
-            if (drop[k]) continue;
-            st.in_deg[in.to[kept[k]]]++;
-            st.out_deg[f]++;
-            ++nnz;
+    std::vector<uint64_t> nnz_t(T, 0);
+    run_threads(T, [&](unsigned t) {
+        uint64_t c = 0;
+        for (uint32_t f = cut[t]; f < cut[t + 1]; ++f) {
+            if (dangling[f]) continue;
+            for (uint64_t k = out_ptr[f]; k < out_ptr[f + 1]; ++k) {
+                if (drop[k]) continue;
+                __atomic_fetch_add(&st.in_deg[in.to[kept[k]]], 1u, __ATOMIC_RELAXED);
+                st.out_deg[f]++;
+                ++c;
+            }
         }
-    }
+        nnz_t[t] = c;
+    });
+    uint64_t nnz = 0;
+    for (unsigned t = 0; t < T; ++t) nnz += nnz_t[t];
     g.nnz = nnz;
     pc.in = in;
     return ET_OK;
@@ -538,12 +576,16 @@ int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& pc, std:
         err = "bad segment";
         return ET_E_INVALID_ARG;
     }
+    const bool stats = getenv("ET_BUILD_STATS") != nullptr;
+    const double t0 = now_s();
     RowSums sums;
     PeerStats st;
     int rc = filter_edges(in, pc, sums, st, err);
     if (rc) return rc;
+    const double t1 = now_s();
     HostGraph& g = pc.g;
     if ((rc = layout_common(in.n, in.member, g.values_are_u32, pc.dangling, st, opt, g, pc.order, err))) return rc;
+    if (stats) fprintf(stderr, "[et build] filter %.3f s, order and geometry %.3f s\n", t1 - t0, now_s() - t1);
     {
         const char* e = getenv("ET_AFFINITY");
         const bool wanted = e ? atoi(e) != 0 : opt.reused;      // pays off after thousands of converges of the same graph
@@ -551,8 +593,10 @@ int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& pc, std:
             cluster_cold_sources(pc, st, opt);
     }
     // ---- 6. per-position source factors ------------------------------------------------------
+    const double t2 = now_s();
     fill_factors(g, pc.order.data(), g.geo.n_active, [&](uint32_t i) { return g.values_are_u32 ? Fr::from_u64(sums.u64[i]) : sums.fr[i]; },
                  [&](uint32_t i) { return g.values_are_u32 ? 1.0 / (double)sums.u64[i] : (double)(1.0L / sums.ld[i]); });
+    if (stats) fprintf(stderr, "[et build] factors %.3f s\n", now_s() - t2);
     return ET_OK;
 }
 
@@ -686,7 +730,9 @@ struct AttesterWalk {
             const uint32_t p = g.pos_of_ext[ext];
             return ((uint64_t)(geo.n_chunks > 1 ? geo.chunk_of_local(p % stride) : 0u) << 32) | p;
         };
-        std::sort(by_pos.begin(), by_pos.end(), [&](uint32_t a, uint32_t b) { return visit_key(a) < visit_key(b); });
+        // one share, one exchange per iteration: position = rank in `order`, which is how by_pos was filled
+        const bool in_order = geo.n_seg == 1 && geo.n_chunks == 1 && std::is_sorted(by_pos.begin(), by_pos.end(), [&](uint32_t a, uint32_t b) { return visit_key(a) < visit_key(b); });
+        if (!in_order) parallel_sort(by_pos.begin(), by_pos.end(), [&](uint32_t a, uint32_t b) { return visit_key(a) < visit_key(b); }, T);
         const uint32_t n_walk = (uint32_t)by_pos.size();
         std::vector<uint64_t> pos_edges((size_t)n_walk + 1, 0);
         for (uint32_t i = 0; i < n_walk; ++i) pos_edges[i + 1] = pos_edges[i] + (pc.out_ptr[by_pos[i] + 1] - pc.out_ptr[by_pos[i]]);
@@ -1080,6 +1126,7 @@ int fill_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned T,
                         e_src[p] = e.pf;
                         e_idx[p] = e.h;
                     });
+        const double t_b = now_s();
         // (b) per-workgroup lists: thread t owns a contiguous range of workgroups
         const uint32_t B64 = geo.f64_blocks;
         std::vector<uint32_t> owner_of_block(B64, 0);
@@ -1094,7 +1141,9 @@ int fill_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned T,
                     if (g.values_are_u32) g.bk_val_u32[q] = src.value_u32(e.h);
                     else g.bk_val_fr[q] = src.value_fr(e.h);
                 });
+        const double t_c = now_s();
         // (c) the workgroups of the exact blocked sweep, when the geometry asks for them
+        if (getenv("ET_BUILD_STATS")) fprintf(stderr, "[et build] f64 lists %.3f s (from %.3f)\n", t_c - t_b, t_b);
         if (geo.fr_blocks) {
             const bool wide = geo.fr_compact == 2;
             g.fb_col.resize(g.nnz_local);
@@ -1118,6 +1167,7 @@ int fill_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned T,
         }
     }
     if (getenv("ET_BUILD_STATS")) {
+        fprintf(stderr, "[et build] edge lists done at %.3f s\n", now_s());
         for (int exact = 0; exact < 2; ++exact) {
             const SweepStats ss = sweep_stats(g, exact != 0);
             if (ss.blocks)
@@ -1267,10 +1317,14 @@ int fill_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned T,
 
 template <class Src>
 int lay_out_segment(HostGraph& g, const BuildOpts& opt, Src& src, unsigned T, std::string& err) {
+    const double t0 = now_s();
     DealtSegment ds;
     int rc = deal_segment(g, opt, src, ds);
     if (rc) return rc;
-    return fill_segment(g, opt, src, T, ds, err);
+    const double t1 = now_s();
+    rc = fill_segment(g, opt, src, T, ds, err);
+    if (getenv("ET_BUILD_STATS")) fprintf(stderr, "[et build] deal %.3f s, edge lists %.3f s\n", t1 - t0, now_s() - t1);
+    return rc;
 }
 
 }  // namespace
@@ -1299,13 +1353,17 @@ SweepStats sweep_stats(const HostGraph& g, bool exact) {
     return ss;
 }
 
-int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index, HostGraph& g, std::string& err) {
+int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg_index, HostGraph& g, std::string& err, bool last_share) {
     if (seg_index >= pc.g.geo.n_seg) { err = "bad segment"; return ET_E_INVALID_ARG; }
-    // everything that does not depend on the segment: filter results, order, positions, factors
-    g = pc.g;
+    // everything that does not depend on the segment: filter results, order, positions, factors (taken over instead of
+    // copied when no other share will be cut from this common part)
+    const double t0 = now_s();
+    if (last_share) g = std::move(const_cast<PlanCommon&>(pc).g);
+    else g = pc.g;
     g.geo.set_share(seg_index);
     const unsigned T = host_threads();
     AttesterWalk src(pc, g, T);
+    if (getenv("ET_BUILD_STATS")) fprintf(stderr, "[et build] copy of the common part and visit order %.3f s\n", now_s() - t0);
     if (g.geo.vec_len >= COL_LOCAL_MASK) { err = "more than 2^29 entries in a share's gather vector"; return ET_E_UNSUPPORTED; }
     BuildOpts o = opt;
     if (getenv("ET_CLUSTER_SHARES")) o.cluster_cited = true;     // measurement knob: such a share steps but cannot pack
@@ -1359,7 +1417,7 @@ int build_graph(const BuildInput& in, const BuildOpts& opt, HostGraph& g, std::s
     PlanCommon pc;
     int rc = plan_common(in, opt, pc, err);
     if (rc) return rc;
-    return plan_segment(pc, opt, opt.seg, g, err);
+    return plan_segment(pc, opt, opt.seg, g, err, true);
 }
 
 }  // namespace et

@@ -124,7 +124,8 @@ struct PlanCommon {
     std::vector<uint32_t> order;
 };
 int plan_common(const BuildInput& in, const BuildOpts& opt, PlanCommon& out, std::string& err);
-int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg, HostGraph& out, std::string& err);
+// last_share: no further share will be cut from `pc` (its common part is handed over rather than copied; pc.g is empty afterwards)
+int plan_segment(const PlanCommon& pc, const BuildOpts& opt, uint32_t seg, HostGraph& out, std::string& err, bool last_share = false);
 
 // A share laid out by a process that never sees the whole attestation list (several processes, each holding the
 // attestations of its own attesters).  The per-peer statistics are summed over the processes; every process then derives the
@@ -180,6 +181,24 @@ inline void run_threads(unsigned count, F f) {
     for (unsigned t = 1; t < count; ++t) th.emplace_back([&f, t]() { f(t); });
     f(0);
     for (auto& x : th) x.join();
+}
+
+// std::sort on the host threads: the range in `count` pieces sorted side by side, then merged pairwise (the same result as
+// std::sort for a strict weak order without equal elements, which is what the planner's orders are: every one ends in
+// the peer's index)
+template <typename It, typename Cmp>
+inline void parallel_sort(It first, It last, Cmp cmp, unsigned count) {
+    const size_t len = (size_t)(last - first);
+    if (count <= 1 || len < 65536) { std::sort(first, last, cmp); return; }
+    unsigned pieces = 1;
+    while (pieces * 2 <= count) pieces *= 2;
+    auto cut = [&](unsigned i) { return first + (ptrdiff_t)(len * i / pieces); };
+    run_threads(pieces, [&](unsigned t) { std::sort(cut(t), cut(t + 1), cmp); });
+    for (unsigned width = 1; width < pieces; width *= 2)
+        run_threads(pieces / (2 * width), [&](unsigned t) {
+            const unsigned i = t * 2 * width;
+            std::inplace_merge(cut(i), cut(i + width), cut(i + 2 * width), cmp);
+        });
 }
 
 }  // namespace et
