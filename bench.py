@@ -481,6 +481,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="N = 1, workload auto: only the 1M-peer graph, not the other configurations")
     ap.add_argument("--chunks", type=int, default=1, help="N > 1: exchange a segment in this many pieces beside the iteration's launches (1 = one all-gather per iteration)")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--value-max", type=int, default=255, help="graph workloads: opinions are drawn from 1..value_max (255: the reference's u8; 4294967295: the 32-bit stress set)")
+    ap.add_argument("--alpha", type=float, default=0.0, help="graph workloads: damping of the f64 variant, pre-trust = the initial scores (0: the reference's update)")
     ap.add_argument("--c5-sets", type=int, default=C5_SETS, help="small-set workload: number of sets")
     ap.add_argument("--c5-slots", type=int, default=C5_SLOTS, help="small-set workload: slots per set (<= 1024)")
     args = ap.parse_args()
@@ -525,7 +527,8 @@ def main():
     elif wl == "c5":
         line = bench_small_sets(args, world, rank, device, red, args.steps, args.warmup, with_cpu)
     else:
-        line = bench_graph(args, wl, world, rank, device, red, args.steps, args.warmup, with_cpu)
+        line = bench_graph(args, wl, world, rank, device, red, args.steps, args.warmup, with_cpu and args.value_max == 255,
+                           value_max=args.value_max, alpha=args.alpha)
         if args.workload == "auto" and world == 1 and not args.no_extras:
             # the other single-GPU configurations, briefly, inside the same line
             saved = args.variant
