@@ -102,7 +102,10 @@ int layout_common(uint32_t n, const uint8_t* member, bool values_are_u32, const 
         const uint32_t win_hi = getenv("ET_FR_SWEEP_MAX_ROWS") ? (uint32_t)atoll(getenv("ET_FR_SWEEP_MAX_ROWS")) : 0xFFFFFFFFu;
         const uint32_t win_lo = getenv("ET_FR_SWEEP_MIN_ROWS") ? (uint32_t)atoll(getenv("ET_FR_SWEEP_MIN_ROWS")) : (1u << 14);
         const bool window = geo.rows_cap >= win_lo && geo.rows_cap <= win_hi;
-        const bool wide = st.value_max > 255 && !getenv("ET_FR_SWEEP_BYTES_ONLY");   // 32-bit opinions: 40-byte rows
+        // 32-bit opinions: 38-byte rows, which hold the sum of fewer than 2^17 products of 288 bits
+        uint32_t in_deg_max = 0;
+        if (st.value_max > 255) for (uint32_t d : st.in_deg) in_deg_max = std::max(in_deg_max, d);
+        const bool wide = st.value_max > 255 && in_deg_max < FR_U32_MAX_IN_DEGREE && !getenv("ET_FR_SWEEP_BYTES_ONLY");
         bytes_only = bytes_only && (st.value_max <= 255 || wide);
         if (bytes_only && window) {
             // whole rounds of 256 workgroups (one per CU), as few as the rows' LDS footprint allows: every round

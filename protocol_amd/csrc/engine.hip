@@ -730,8 +730,7 @@ struct StepArgsFrB {
     const uint4* x;
     uint4* y;
     uint4* own;
-    const uint4* scale288;    // inv(sum) * 2^288 per row
-    const uint4* scale576;    // inv(sum) * 2^576 per row (WIDE: the row is reduced to its plain score first)
+    const uint4* scale288;    // per row: inv(sum) * 2^288, or inv(sum) * 2^320 (WIDE)
     uint4* sum_part;          // [fr_blocks][2]
     uint32_t* chg_part;       // [fr_blocks]
     Geometry geo;
@@ -757,6 +756,15 @@ __global__ void k_scale_288(const uint4* __restrict__ scale576, uint4* __restric
     u256_store(scale288 + 2 * i, acc_redc288(t));
 }
 
+// inv(sum) * 2^320 from inv(sum) * 2^576: what the rows of 32-bit opinions are multiplied by
+__global__ void k_scale_320(const uint4* __restrict__ scale576, uint4* __restrict__ scale320, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    U256 two32 = u256_zero();
+    two32.v[1] = 1u;
+    u256_store(scale320 + 2 * i, fr_mul_redc288(u256_load(scale576 + 2 * i), two32));
+}
+
 // COMPACT: a row's sum as nine 32-bit limbs, stored as four 64-bit words [4][RB] followed by the top limbs [RB]
 // (36 bytes per row, so one workgroup per CU covers 1M rows in ONE round and the vector crosses every L2 once).
 // An edge adds its 264-bit product word by word with LDS atomics that return the old word: the add that wraps a word
@@ -767,9 +775,10 @@ __global__ void k_scale_288(const uint4* __restrict__ scale576, uint4* __restric
 // PHASED: as for the f64 sweep.
 // PACKED: 5-byte edge records (one 32-bit record and the opinion byte) in place of 7 bytes (source, row, opinion).
 // WIDE: 32-bit opinions (the reference's opinion is any field element, native.rs:128; integers above a byte take this
-// form).  The product has 288 bits and a row's sum up to 2^310, so the top of a row is a 64-bit word (40 bytes per row,
-// [5][RB] words) and a row is reduced to its plain score before the product with its factor (208 instead of 144 limb
-// multiply-adds per row), as the row-per-lane kernel does.
+// form).  The product has 288 bits; a row with fewer than 2^17 in-edges (the planner checks) sums to less than 2^304, so a
+// row carries sixteen more bits beside its nine limbs (38 bytes: the tenth limbs of two rows share a 32-bit word), the
+// add that wraps the ninth limb sending its carry there.  The row's ten limbs are multiplied by inv(sum) * 2^320 and
+// reduced in one pass of ten rounds (160 limb multiply-adds per row).
 template <bool COMPACT, bool PHASED = false, bool PACKED = false, bool WIDE = false>
 __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     static_assert(!(PACKED && PHASED), "runs of a chunked list do not start on a 64-edge boundary");
@@ -788,9 +797,9 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     const uint32_t stride = a.geo.seg_stride();
     const size_t my_base = a.geo.own_off;
     uint32_t* const top_l = reinterpret_cast<uint32_t*>(colsum_l + 4 * (size_t)RB);   // COMPACT: limb 8 of every row
-    unsigned long long* const top64_l = colsum_l + 4 * (size_t)RB;                    // WIDE: limbs 8 and 9
+    uint32_t* const ext_l = top_l + RB;                                               // WIDE: limb 9, sixteen bits per row
     const bool first_phase = !PHASED || a.phase == 0, last_phase = !PHASED || a.phase + 1 == a.n_phases;
-    const uint32_t lds_words = WIDE ? 5 * RB : (COMPACT ? 4 * RB + RB / 2 : 8 * RB);   // RB is a multiple of 16
+    const uint32_t lds_words = WIDE ? 4 * RB + RB / 2 + RB / 4 : (COMPACT ? 4 * RB + RB / 2 : 8 * RB);   // RB is a multiple of 16
     for (uint32_t i = threadIdx.x; i < lds_words; i += 1024) colsum_l[i] = first_phase ? 0ull : a.acc_g[(size_t)b * lds_words + i];
     // partial-sum slots no workgroup writes: zero, whatever the caller's buffer held (see fr_zero_unused_tail)
     if (last_phase) fr_zero_unused_tail(a.y, a.geo, a.geo.fr_dblocks, 1024);
@@ -827,8 +836,8 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     auto carry_into = [&](uint32_t slot, uint32_t k) {
         for (; k < 4; ++k)
             if (atomicAdd(colsum_l + (size_t)k * RB + slot, 1ull) != ~0ull) return;
-        if (WIDE) atomicAdd(top64_l + slot, 1ull);
-        else atomicAdd(top_l + slot, 1u);
+        if (!WIDE) atomicAdd(top_l + slot, 1u);
+        else if (atomicAdd(top_l + slot, 1u) == 0xFFFFFFFFu) atomicAdd(ext_l + (slot >> 1), 1u << (16 * (slot & 1)));
     };
     auto add_edge = [&](uint32_t slot, uint32_t v, const uint4& lo, const uint4& hi) {
         unsigned long long* p = colsum_l + slot;
@@ -854,8 +863,12 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             // old + addend wrapped  <=>  old > ~addend
             const bool c1 = o0 > ~w0, c2 = o1 > ~w1, c3 = o2 > ~w2;
             w4 += o3 > ~w3 ? 1u : 0u;
-            if (WIDE) atomicAdd(top64_l + slot, (unsigned long long)w4);
-            else if (w4) atomicAdd(top_l + slot, (uint32_t)w4);
+            if (WIDE) {                                     // w4 <= 2^32: its low word into limb 8, what wraps into limb 9
+                const uint32_t low = (uint32_t)w4;
+                const uint32_t old = atomicAdd(top_l + slot, low);
+                const uint32_t up = (uint32_t)(w4 >> 32) + (old > ~low ? 1u : 0u);
+                if (up) atomicAdd(ext_l + (slot >> 1), up << (16 * (slot & 1)));
+            } else if (w4) atomicAdd(top_l + slot, (uint32_t)w4);
             if (c1) carry_into(slot, 1);
             if (c2) carry_into(slot, 2);
             if (c3) carry_into(slot, 3);
@@ -950,7 +963,6 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     }
 
     U256 dacc = u256_zero();                              // field sum of this thread's dangling rows' scores
-    U256 wsum = u256_zero();                              // WIDE: field sum of the plain scores of this thread's other rows
     Acc10 traw = acc10_zero();                            // integer sum of this thread's T
     uint32_t changed = 0;
     // eight 64-bit column sums, 32 bits apart, as ten limbs
@@ -962,14 +974,8 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
                 t[2 * j] = (uint32_t)w;
                 t[2 * j + 1] = (uint32_t)(w >> 32);
             }
-            if (WIDE) {
-                const unsigned long long w = top64_l[lr];
-                t[8] = (uint32_t)w;
-                t[9] = (uint32_t)(w >> 32);
-            } else {
-                t[8] = top_l[lr];
-                t[9] = 0;
-            }
+            t[8] = top_l[lr];
+            t[9] = WIDE ? (ext_l[lr >> 1] >> (16 * (lr & 1))) & 0xFFFFu : 0u;
             return;
         }
         uint64_t c = 0;
@@ -1005,36 +1011,25 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             if (WIDE) { c += t[8]; t[8] = (uint32_t)c; t[9] += (uint32_t)(c >> 32); }
             else t[8] += (uint32_t)c;
         }
-        if (WIDE) {
-            // ten limbs: the plain score first (one reduction), then its product with the factor
-            Acc full = acc_zero();
-#pragma unroll
-            for (int i = 0; i < 10; ++i) full.v[i] = t[i];
-            const U256 v = acc_redc288(full);
-            wsum = fr_add(wsum, v);
-            // changed: against the old exchanged entry, as below (so the last step forms the scaled entry too)
-            const U256 xs = fr_mul_redc288(v, u256_load(a.scale576 + 2 * (size_t)row));
-            changed += u256_eq(xs, u256_load(a.x + 2 * (my_base + row))) ? 0u : 1u;
-            u256_store(a.y + 2 * (my_base + row), a.final_step ? v : xs);
-            continue;
-        }
         {
             uint64_t c = 0;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
+            for (int i = 0; i < (WIDE ? 10 : 9); ++i) {
                 c += (uint64_t)traw.v[i] + t[i];
                 traw.v[i] = (uint32_t)c;
                 c >>= 32;
             }
-            traw.v[9] += (uint32_t)c;
+            if (!WIDE) traw.v[9] += (uint32_t)c;
         }
-        const U256 xs = fr_mul9_redc288(t, u256_load(a.scale288 + 2 * (size_t)row));
+        // the exchanged entry: T * inv(sum); the resident factor carries 2^288 (nine limbs, nine rounds) or 2^320 (ten)
+        const U256 factor = u256_load(a.scale288 + 2 * (size_t)row);
+        const U256 xs = WIDE ? fr_mul10_redc320(t, factor) : fr_mul9_redc288(t, factor);
         const U256 old = u256_load(a.x + 2 * (my_base + row));
         changed += u256_eq(xs, old) ? 0u : 1u;
         if (a.final_step) {
             Acc full = acc_zero();
 #pragma unroll
-            for (int i = 0; i < 9; ++i) full.v[i] = t[i];
+            for (int i = 0; i < (WIDE ? 10 : 9); ++i) full.v[i] = t[i];
             u256_store(a.y + 2 * (my_base + row), acc_redc288(full));
         } else {
             u256_store(a.y + 2 * (my_base + row), xs);
@@ -1060,13 +1055,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
         }
     }
     // per wavefront: integer sum of the T, field sum of the dangling rows' scores (leading workgroups only), count
-    if (WIDE) {
-        wsum = fr_wave_sum(wsum);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) traw.v[i] = wsum.v[i];
-    } else {
-        acc10_group_sum(traw, 64);
-    }
+    acc10_group_sum(traw, 64);
     if (b < a.geo.fr_dblocks) dacc = fr_wave_sum(dacc);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) changed += __shfl_xor(changed, off, 64);
@@ -1079,7 +1068,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     __syncthreads();
     // the first wavefront adds the sixteen partial results, one per lane
     if (wave == 0) {
-        Acc10 r10 = acc10_zero();                         // at most 2432 rows below 2^287 each: ten limbs
+        Acc10 r10 = acc10_zero();
         U256 d = u256_zero();
         uint32_t ch = 0;
         if (lane < 16) {
@@ -1088,21 +1077,14 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             d = u256_load(red_l + 2 * lane);
             ch = red_c[lane];
         }
-        U256 others;                                      // score sum of the rows with opinions
-        if (WIDE) {                                       // sixteen field sums (the lanes beyond hold zero)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) others.v[i] = r10.v[i];
-            others = fr_wave_sum(others);
-        } else {
-            acc10_group_sum(r10, 16);
-            others = acc_redc288(acc_from_acc10(r10));    // the reduced integer sum of the T
-        }
+        acc10_group_sum(r10, 16);
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) ch += __shfl_xor(ch, off, 64);
         if (b < a.geo.fr_dblocks) d = fr_wave_sum(d);
         if (lane == 0) {
-            // score sum of the workgroup's rows: the dangling rows' plain scores plus the others'
-            u256_store(a.sum_part + 2 * (size_t)b, fr_add(d, others));
+            // score sum of the workgroup's rows: the dangling rows' plain scores plus the reduced integer sum of the T
+            // (at most 4400 rows below 2^287 each, or 4240 below 2^304: ten limbs)
+            u256_store(a.sum_part + 2 * (size_t)b, fr_add(d, acc_redc288(acc_from_acc10(r10))));
             a.chg_part[b] = ch;
             if (b < a.geo.fr_dblocks) u256_store(a.y + 2 * (my_base + a.geo.rows_cap + b), d);   // partial sum slot b
         }
@@ -1517,7 +1499,8 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
             for (const void* f : sweeps) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
             // the sweep multiplies unreduced row sums by inv(sum) * 2^288 (the resident factors carry 2^576)
             if ((rc = dev_alloc(&g->d_fb_scale, stride * 2, tot))) return rc;
-            hipLaunchKernelGGL(k_scale_288, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, 0, g->d_scale_fr, g->d_fb_scale, stride);
+            if (h.geo.fr_compact == 2) hipLaunchKernelGGL(k_scale_320, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, 0, g->d_scale_fr, g->d_fb_scale, stride);
+            else hipLaunchKernelGGL(k_scale_288, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, 0, g->d_scale_fr, g->d_fb_scale, stride);
             HIP_TRY(hipDeviceSynchronize());
         }
         if ((h.geo.n_seg == 1 && (rc = dev_alloc(&g->out_fr, (size_t)h.n * 2, tot))) || (rc = dev_alloc(&g->d_frsum_part, (size_t)STATS_RING * g->n_fr_parts * 2, tot)) ||
@@ -1635,7 +1618,7 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
         const size_t ringb = (size_t)(iteration % STATS_RING) * n_fr_parts;
         fb.ptr = d_fb_ptr; fb.grp = d_fb_grp; fb.col = d_fb_col; fb.row = d_fb_row; fb.val = d_fb_val; fb.x = x; fb.y = y;
         fb.rec = d_fb_rec; fb.cbase = d_fb_cbase; fb.cptr = d_fb_cptr; fb.rec_shift = fr_rec_shift;
-        fb.own = own_fr; fb.scale288 = d_fb_scale; fb.scale576 = d_scale_fr; fb.sum_part = d_frsum_part + 2 * ringb; fb.chg_part = d_chg_part + ringb;
+        fb.own = own_fr; fb.scale288 = d_fb_scale; fb.sum_part = d_frsum_part + 2 * ringb; fb.chg_part = d_chg_part + ringb;
         fb.geo = geo; fb.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u; fb.inv_nm1_w = to_u256(inv_nm1_w);
         fb.inv_nm1_w576 = to_u256((Fr::from_raw(inv_nm1_w) * Fr::one().pow2k(288)).to_raw());
         fb.phase_ptr = d_fb_phase; fb.acc_g = d_fr_acc; fb.n_phases = geo.n_chunks;
@@ -1644,7 +1627,7 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
         for (uint32_t q = phase < 0 ? 0u : (uint32_t)phase; q < (phase < 0 ? geo.n_chunks : (uint32_t)phase + 1); ++q) {
             fb.phase = q;
             const dim3 grid(geo.fr_blocks), wg(1024);
-            const size_t lds = (size_t)geo.fr_rb * (geo.fr_compact == 2 ? 40 : (geo.fr_compact ? 36 : 64));
+            const size_t lds = (size_t)geo.fr_rb * (geo.fr_compact == 2 ? 38 : (geo.fr_compact ? 36 : 64));
             if (geo.n_chunks > 1) {
                 if (geo.fr_compact) hipLaunchKernelGGL((k_step_fr_blocked<true, true>), grid, wg, lds, st, fb);
                 else hipLaunchKernelGGL((k_step_fr_blocked<false, true>), grid, wg, lds, st, fb);

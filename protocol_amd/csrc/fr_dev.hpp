@@ -248,6 +248,35 @@ ET_DEV U256 fr_mul9_redc288(const uint32_t* a9, const U256& b) {
     }
     return u256_sub_p_if_geq(r);
 }
+// a (10 limbs, below 2^304) * b * 2^-320 mod r, canonical: the same pass with one more limb and one more reduction round
+// (the quotient a * b / 2^320 stays below 2^238, so one conditional subtraction brings the result below r).  Requires b < r.
+ET_DEV U256 fr_mul10_redc320(const uint32_t* a10, const U256& b) {
+    uint64_t lohi = 0;
+    uint32_t top = 0;
+    uint32_t m[10];
+    U256 r;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const int k = i - j;
+            if (k >= 0 && k < 8) col_mac(lohi, top, a10[j], b.v[k]);
+        }
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const int k = i - j;
+            if (j < i && k >= 0 && k < 8) col_mac(lohi, top, m[j], FR_P[k]);
+        }
+        if (i < 10) {
+            m[i] = (uint32_t)lohi * FR_N0_32;
+            col_mac(lohi, top, m[i], FR_P[0]);               // the column's low word becomes zero
+            (void)col_shift(lohi, top);
+        } else {
+            r.v[i - 10] = col_shift(lohi, top);
+        }
+    }
+    return u256_sub_p_if_geq(r);
+}
 // a * b * 2^-256 mod r for a below 2^256 and b < r, NOT brought below r (below 2^256 and congruent): acc_mac followed
 // by acc_redc_loose<8>, as one pass over the columns
 ET_DEV U256 fr_mul_redc_loose8(const U256& a, const U256& b) {

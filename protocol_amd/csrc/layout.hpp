@@ -72,7 +72,8 @@ inline uint32_t dangling_blocks(uint32_t blocks, uint32_t groups_per_block, uint
     return d < blocks ? d : blocks;
 }
 static const uint32_t FR_RB_MAX_COMPACT = 4400, FR_RB_MAX_WIDE = 2432;
-static const uint32_t FR_RB_MAX_U32 = 3968;   // 32-bit opinions: 40 bytes of LDS per row
+static const uint32_t FR_RB_MAX_U32 = 4240;   // 32-bit opinions: 38 bytes of LDS per row
+static const uint32_t FR_U32_MAX_IN_DEGREE = 1u << 17;   // ... which hold a row's sum while it has fewer in-edges than this
 // A source index in an edge record: segment in the top 3 bits, local row below.
 static const uint32_t COL_SEG_SHIFT = 29;
 static const uint32_t COL_LOCAL_MASK = (1u << COL_SEG_SHIFT) - 1;
@@ -95,8 +96,8 @@ struct Geometry {
     uint32_t f64_dblocks;
     // exact blocked sweep (integer opinions, 16K rows per share and more; 0 workgroups = not used): the same deal with a
     // row's unreduced sum in LDS.  fr_compact == 1: byte opinions, nine 32-bit limbs per row (36 bytes, carries propagated
-    // as the edges arrive), up to FR_RB_MAX_COMPACT rows per workgroup; 2: 32-bit opinions, ten limbs (40 bytes), up to
-    // FR_RB_MAX_U32 rows; 0 (a measurement knob, byte opinions): eight 64-bit column sums (64 bytes, no carries until the
+    // as the edges arrive), up to FR_RB_MAX_COMPACT rows per workgroup; 2: 32-bit opinions, nine limbs and sixteen bits
+    // (38 bytes), up to FR_RB_MAX_U32 rows, graphs whose rows have fewer than FR_U32_MAX_IN_DEGREE in-edges; 0 (a measurement knob, byte opinions): eight 64-bit column sums (64 bytes, no carries until the
     // row is folded), up to FR_RB_MAX_WIDE rows.
     uint32_t fr_blocks, fr_rb, fr_dblocks, fr_compact;
     // Chunked exchange (several GPUs): a segment travels in n_chunks pieces of chunk_rows rows (the last piece takes

@@ -51,7 +51,7 @@ def test_1m_peers_16m_attestations_with_32_bit_opinions():
                                                          n_threads=c_oracle.max_threads(), want_ld=True)
     assert rc == 0
     g = pa.Graph(n, frm, to, value_u32=val, member=member)
-    assert int(g.info.nnz) == nnz and int(g.info.exact_sweep_blocks) == 512     # 40-byte rows: two rounds of 256 workgroups
+    assert int(g.info.nnz) == nnz and int(g.info.exact_sweep_blocks) == 256     # 38-byte rows: one round of 256 workgroups
     assert np.array_equal(g.converge_fr(iters, 1000), exp)
     o64, _ = g.converge_f64(iters, 1000.0)
     assert rel_l1(o64, eld) <= F64_TOL

@@ -243,13 +243,16 @@ def test_both_exact_kernels_above_half_a_million_rows(row_per_lane, monkeypatch)
 
 def test_exact_sweep_with_32_bit_opinions(monkeypatch):
     """Opinions above a byte (the reference's opinion is any field element, native.rs:128): the exact variant runs the blocked
-    sweep with ten-limb rows, the f64 sweep 8-byte packed records.  Hubs rated by thousands with the largest opinion
-    stress the carries of a row's 320-bit sum."""
+    sweep with rows of nine limbs and sixteen bits, the f64 sweep 8-byte packed records.  Hubs rated by tens of thousands
+    with the largest opinion stress the carries of a row's sum."""
     rng = np.random.default_rng(78)
     n = 600000
-    member, frm, to, val = random_graph(rng, n, 3, 0.0, 0.02, 2**32 - 1, True)
+    member, frm, to, val = random_graph(rng, n, 3, 0.0, 0.02, 2**32 - 1, False)
+    sel = rng.random(len(frm)) < 0.1                       # three hubs of about 60 000 in-edges each
+    to[sel] = rng.integers(0, 3, sel.sum(), dtype=np.uint32)
     big = np.flatnonzero(to < 3)
     val[big[: len(big) // 2]] = 0xFFFFFFFF
+    assert 30000 < np.bincount(to[frm != to], minlength=n).max() < 2**17
     rc, exp, nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=5, initial=1000,
                                                   n_threads=c_oracle.max_threads())
     assert rc == 0
@@ -278,6 +281,19 @@ def test_exact_sweep_with_32_bit_opinions(monkeypatch):
     g = pa.Graph(n, frm, to, value_u32=val, member=member, variants=1)
     assert int(g.info.exact_sweep_blocks) == 0
     assert np.array_equal(g.converge_fr(5, 1000), exp)
+    g.close()
+    monkeypatch.delenv("ET_FR_SWEEP_BYTES_ONLY")
+    monkeypatch.delenv("ET_FR_UNPACKED")
+    monkeypatch.delenv("ET_F64_UNPACKED")
+    # a row with 2^17 in-edges or more does not fit the sweep's sixteen spare bits: such a graph keeps the row-per-lane kernel
+    member, frm, to, val = random_graph(rng, n, 3, 0.0, 0.02, 2**32 - 1, True)     # three hubs of about 180 000 in-edges
+    assert np.bincount(to[frm != to], minlength=n).max() >= 2**17
+    rc, exp, nnz, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=3, initial=1000,
+                                                  n_threads=c_oracle.max_threads())
+    assert rc == 0
+    g = pa.Graph(n, frm, to, value_u32=val, member=member, variants=1)
+    assert int(g.info.exact_sweep_blocks) == 0
+    assert np.array_equal(g.converge_fr(3, 1000), exp)
 
 
 def test_full_size_benchmark_graph_parity():
