@@ -184,6 +184,13 @@ struct StepArgsF64B {
     uint32_t phase, n_phases;
     uint32_t bar_period;      // batches between two barriers of the sweep
     uint32_t bar_first_256;   // the first one after this many 256ths of the workgroup's batches
+    // A whole converge on one GPU (run_f64): the first step reads a vector that is kept from converge to converge, so
+    // the plain scores of the dangling rows (`own`) have not been reset: their old score is `initial`.  The last step
+    // writes the scores where the caller reads them, out[peer[row]] (slot order), in place of its segment of y.
+    uint32_t first_step;
+    double initial;
+    double* out;
+    const uint32_t* peer;     // [rows_cap] slot of the peer at a position, ~0 = none
 };
 
 // PHASED: one of several launches of an iteration (chunked exchange); otherwise the launch is the whole iteration and
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     // The rows' epilogue needs, per row, its group entry and then the old score and the factor: two dependent trips to
     // memory with nothing else left to do.  The first four rows of every thread (all of them when the workgroup holds
     // at most 4096) are asked for here, before the sweep, and wait in registers.
-    uint32_t pgrp[4];
+    uint32_t pgrp[4], ppeer[4];
     double pold[4], psc[4], ppt[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -237,12 +244,15 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
         const uint32_t lr = threadIdx.x + u * 1024;
         const uint32_t row = pgrp[u] * BLOCK_GROUP + lr % BLOCK_GROUP;
         pold[u] = psc[u] = ppt[u] = 0.0;
+        ppeer[u] = 0xFFFFFFFFu;
         if (pgrp[u] != 0xFFFFFFFFu) {                      // rows beyond the members read a valid address and are dropped later
             // raw form: a peer with opinions keeps no plain score between iterations (its old one is the exchanged entry
             // divided by the factor); a peer without has factor zero and keeps its plain score in `own`
-            pold[u] = RAW && row_is_dangling(a.geo, row) ? a.own[row] : xr[my_base + row];
+            if (RAW && row_is_dangling(a.geo, row)) pold[u] = a.first_step ? a.initial : a.own[row];
+            else pold[u] = xr[my_base + row];
             if (RAW) psc[u] = a.scale[row];
             if (HAS_ALPHA) ppt[u] = a.pretrust[my_base + row];
+            if (a.out) ppeer[u] = a.peer[row];
         }
     }
     __syncthreads();
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     double res = 0.0, tot = 0.0, dacc = 0.0;
     // four rows per thread at a time: their group entries, then their old scores and factors are requested together
     for (uint32_t lr0 = threadIdx.x; lr0 < RB; lr0 += 4 * 1024) {
-        uint32_t grp[4], row[4];
+        uint32_t grp[4], row[4], peer[4];
         bool live[4], dang[4];
         double old[4], sc[4], pt[4];
         const bool first = lr0 == threadIdx.x;             // this pass was asked for before the sweep
@@ -354,12 +364,15 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
             dang[u] = q >= a.geo.n_active_pad && q < (uint64_t)a.geo.n_active_pad + a.geo.n_dangling;
             live[u] = grp[u] != 0xFFFFFFFFu && (active || dang[u]);
             old[u] = sc[u] = pt[u] = 0.0;
+            peer[u] = 0xFFFFFFFFu;
             if (first) {
-                if (live[u]) { old[u] = pold[u]; sc[u] = psc[u]; pt[u] = ppt[u]; }
+                if (live[u]) { old[u] = pold[u]; sc[u] = psc[u]; pt[u] = ppt[u]; peer[u] = ppeer[u]; }
             } else if (live[u]) {
-                old[u] = RAW && dang[u] ? a.own[row[u]] : xr[my_base + row[u]];
+                if (RAW && dang[u]) old[u] = a.first_step ? a.initial : a.own[row[u]];
+                else old[u] = xr[my_base + row[u]];
                 if (RAW) sc[u] = a.scale[row[u]];
                 if (HAS_ALPHA) pt[u] = a.pretrust[my_base + row[u]];
+                if (a.out) peer[u] = a.peer[row[u]];
             }
             if (RAW && live[u] && !dang[u]) old[u] = old[u] / sc[u];
         }
@@ -369,11 +382,11 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
             const double s = acc_l[lr0 + u * 1024];
             double v = dang[u] ? s + (D - old[u]) * a.inv_nm1 : s + dterm;
             if (HAS_ALPHA) v = (1.0 - a.alpha) * v + a.alpha * pt[u];
-            if (RAW) {
-                if (dang[u]) a.own[row[u]] = v;
-                a.y[my_base + row[u]] = a.final_step ? v : v * sc[u];
+            if (RAW && dang[u]) a.own[row[u]] = v;
+            if (a.out) {
+                if (peer[u] != 0xFFFFFFFFu) a.out[peer[u]] = v;
             } else {
-                a.y[my_base + row[u]] = v;
+                a.y[my_base + row[u]] = RAW && !a.final_step ? v * sc[u] : v;
             }
             res += fabs(v - old[u]);
             tot += v;
@@ -744,6 +757,14 @@ struct StepArgsFrB {
     U256 inv_nm1_w576;        // inv(n_valid - 1) * 2^576
     uint32_t bar_period;      // passes between two barriers of the sweep
     uint32_t bar_first_256;   // the first one after this many 256ths of the workgroup's passes
+    // count the rows whose entry changed (one more 32-byte load per row); a converge asks for it on its last step only
+    uint32_t count_changes;
+    // a whole converge on one GPU (run_fr), as for the f64 sweep: dangling rows' old score on the first step, and the
+    // last step's scores written in slot order
+    uint32_t first_step;
+    U256 initial;
+    uint4* out;
+    const uint32_t* peer;
 };
 
 __global__ void k_scale_288(const uint4* __restrict__ scale576, uint4* __restrict__ scale288, size_t n) {
@@ -803,6 +824,14 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     for (uint32_t i = threadIdx.x; i < lds_words; i += 1024) colsum_l[i] = first_phase ? 0ull : a.acc_g[(size_t)b * lds_words + i];
     // partial-sum slots no workgroup writes: zero, whatever the caller's buffer held (see fr_zero_unused_tail)
     if (last_phase) fr_zero_unused_tail(a.y, a.geo, a.geo.fr_dblocks, 1024);
+    // the rows' epilogue starts from their group entries: those of a thread's first four rows are asked for here and
+    // wait in registers through the sweep, one trip to memory less after it
+    uint32_t pgrp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t lr = threadIdx.x + u * 1024;
+        pgrp[u] = lr < RB && last_phase ? a.grp[(size_t)b * (RB / BLOCK_GROUP) + lr / BLOCK_GROUP] : 0xFFFFFFFFu;
+    }
     __syncthreads();
     // the first wavefront prepares the dangling term while the others already sweep; the workgroup next meets at
     // the sweep's own barriers, and the term is read after the barrier that ends the sweep
@@ -990,49 +1019,78 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
         t[9] = (uint32_t)(c >> 32);
     };
     // rows with opinions first (the common case, no dangling arithmetic in the loop), then the dangling rows, which
-    // only the leading workgroups hold
-    for (uint32_t lr = threadIdx.x; lr < RB; lr += 1024) {
-        const uint32_t grp = a.grp[(size_t)b * (RB / BLOCK_GROUP) + lr / BLOCK_GROUP];
-        if (grp == 0xFFFFFFFFu) continue;
-        const uint32_t row = grp * BLOCK_GROUP + lr % BLOCK_GROUP;
-        const uint64_t q = ((uint64_t)(row >> 6) * a.geo.n_seg + a.geo.seg) * 64 + (row & 63);
-        if (q >= a.geo.n_active) continue;
-        // T = sum of opinion * xs (below 2^24 * 2^8 * r) + dangling term (below r): limb 9 stays empty
-        uint32_t t[10];
-        fold_row(lr, t);
-        {
-            uint64_t c = 0;
+    // only the leading workgroups hold.  Two rows per thread at a time: their factors are requested together.
+    constexpr int EP = 2;
+    for (uint32_t k = 0; threadIdx.x + k * 1024 < RB; k += EP) {
+        const uint32_t lr0 = threadIdx.x + k * 1024;
+        uint32_t row[EP], peer[EP];
+        bool act[EP];
+        U256 factor[EP];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                c += (uint64_t)t[i] + sh_pdr[i];
-                t[i] = (uint32_t)c;
-                c >>= 32;
-            }
-            if (WIDE) { c += t[8]; t[8] = (uint32_t)c; t[9] += (uint32_t)(c >> 32); }
-            else t[8] += (uint32_t)c;
+        for (int u = 0; u < EP; ++u) {
+            const uint32_t lr = lr0 + u * 1024;
+            // group entries of the first four rows: asked for before the sweep
+            uint32_t grp = lr < RB ? 0u : 0xFFFFFFFFu;
+            if (k == 0) grp = pgrp[u];
+            else if (k == 2) grp = pgrp[2 + u];
+            else if (lr < RB) grp = a.grp[(size_t)b * (RB / BLOCK_GROUP) + lr / BLOCK_GROUP];
+            row[u] = grp * BLOCK_GROUP + lr % BLOCK_GROUP;
+            const uint64_t q = ((uint64_t)(row[u] >> 6) * a.geo.n_seg + a.geo.seg) * 64 + (row[u] & 63);
+            act[u] = grp != 0xFFFFFFFFu && q < a.geo.n_active;
         }
-        {
-            uint64_t c = 0;
 #pragma unroll
-            for (int i = 0; i < (WIDE ? 10 : 9); ++i) {
-                c += (uint64_t)traw.v[i] + t[i];
-                traw.v[i] = (uint32_t)c;
-                c >>= 32;
+        for (int u = 0; u < EP; ++u) {
+            factor[u] = u256_zero();
+            peer[u] = 0xFFFFFFFFu;
+            if (act[u]) {
+                factor[u] = u256_load(a.scale288 + 2 * (size_t)row[u]);
+                if (a.out) peer[u] = a.peer[row[u]];
             }
-            if (!WIDE) traw.v[9] += (uint32_t)c;
         }
-        // the exchanged entry: T * inv(sum); the resident factor carries 2^288 (nine limbs, nine rounds) or 2^320 (ten)
-        const U256 factor = u256_load(a.scale288 + 2 * (size_t)row);
-        const U256 xs = WIDE ? fr_mul10_redc320(t, factor) : fr_mul9_redc288(t, factor);
-        const U256 old = u256_load(a.x + 2 * (my_base + row));
-        changed += u256_eq(xs, old) ? 0u : 1u;
-        if (a.final_step) {
-            Acc full = acc_zero();
 #pragma unroll
-            for (int i = 0; i < (WIDE ? 10 : 9); ++i) full.v[i] = t[i];
-            u256_store(a.y + 2 * (my_base + row), acc_redc288(full));
-        } else {
-            u256_store(a.y + 2 * (my_base + row), xs);
+        for (int u = 0; u < EP; ++u) {
+            if (!act[u]) continue;
+            // T = sum of opinion * xs (below 2^24 * 2^8 * r) + dangling term (below r): limb 9 stays empty
+            uint32_t t[10];
+            fold_row(lr0 + u * 1024, t);
+            {
+                uint64_t c = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    c += (uint64_t)t[i] + sh_pdr[i];
+                    t[i] = (uint32_t)c;
+                    c >>= 32;
+                }
+                if (WIDE) { c += t[8]; t[8] = (uint32_t)c; t[9] += (uint32_t)(c >> 32); }
+                else t[8] += (uint32_t)c;
+            }
+            {
+                uint64_t c = 0;
+#pragma unroll
+                for (int i = 0; i < (WIDE ? 10 : 9); ++i) {
+                    c += (uint64_t)traw.v[i] + t[i];
+                    traw.v[i] = (uint32_t)c;
+                    c >>= 32;
+                }
+                if (!WIDE) traw.v[9] += (uint32_t)c;
+            }
+            // the exchanged entry: T * inv(sum); the resident factor carries 2^288 (nine limbs, nine rounds) or 2^320 (ten)
+            if (!a.final_step || a.count_changes) {
+                const U256 xs = WIDE ? fr_mul10_redc320(t, factor[u]) : fr_mul9_redc288(t, factor[u]);
+                if (a.count_changes) {
+                    const U256 old = u256_load(a.x + 2 * (my_base + row[u]));
+                    changed += u256_eq(xs, old) ? 0u : 1u;
+                }
+                if (!a.final_step) u256_store(a.y + 2 * (my_base + row[u]), xs);
+            }
+            if (a.final_step) {
+                Acc full = acc_zero();
+#pragma unroll
+                for (int i = 0; i < (WIDE ? 10 : 9); ++i) full.v[i] = t[i];
+                const U256 plain = acc_redc288(full);
+                if (!a.out) u256_store(a.y + 2 * (my_base + row[u]), plain);
+                else if (peer[u] != 0xFFFFFFFFu) u256_store(a.out + 2 * (size_t)peer[u], plain);
+            }
         }
     }
     if (b < a.geo.fr_dblocks) {
@@ -1044,13 +1102,17 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             if (q < a.geo.n_active_pad || q >= (uint64_t)a.geo.n_active_pad + a.geo.n_dangling) continue;
             Acc full = acc_zero();
             fold_row(lr, full.v);
-            const U256 old = u256_load(a.own + 2 * (size_t)row);
+            const U256 old = a.first_step ? a.initial : u256_load(a.own + 2 * (size_t)row);
             fr_add_dangling_term(full, sh_d, old, a.inv_nm1_w);
             const U256 v = acc_redc288(full);
             u256_store(a.own + 2 * (size_t)row, v);
             // a dangling peer has no out-edges: its exchanged entry is never gathered
-            u256_store(a.y + 2 * (my_base + row), a.final_step ? v : u256_zero());
-            changed += u256_eq(v, old) ? 0u : 1u;
+            if (!a.out) u256_store(a.y + 2 * (my_base + row), a.final_step ? v : u256_zero());
+            else {
+                const uint32_t pe = a.peer[row];
+                if (pe != 0xFFFFFFFFu) u256_store(a.out + 2 * (size_t)pe, v);
+            }
+            if (a.count_changes) changed += u256_eq(v, old) ? 0u : 1u;
             dacc = fr_add(dacc, v);
         }
     }
@@ -1178,7 +1240,7 @@ static int dev_upload(T** p, const std::vector<T>& v, uint64_t& total) {
 DeviceGraph::~DeviceGraph() {
     if (device >= 0) (void)hipSetDevice(device);
     void* ptrs[] = {d_send_idx, d_fb_rec, d_fb_cbase, d_fb_cptr, d_bk_ptr, d_bk_grp, d_bk_col, d_bk_row, d_bk_w, d_bk_rec, d_bk_cbase, d_bk_cptr, d_fb_ptr, d_fb_grp, d_fb_col, d_fb_row, d_fb_val, d_work, d_slices, d_col, d_val, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
-                    d_chg_part, d_stat_out, d_bk_phase, d_fb_phase, d_f64_acc, d_fr_acc, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust, d_scale64, d_scale_fr, d_fb_scale, own64, own_fr};
+                    d_chg_part, d_stat_out, d_bk_phase, d_fb_phase, d_f64_acc, d_fr_acc, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust, d_scale64, d_scale_fr, d_fb_scale, own64, own_fr, d_peer, x0_64, x0_fr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* e : ev_begin) (void)hipEventDestroy((hipEvent_t)e);
     for (void* e : ev_end) (void)hipEventDestroy((hipEvent_t)e);
@@ -1360,6 +1422,17 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
     if ((rc = dev_upload(&g->d_slices, h.slices, tot))) return rc;
     if ((rc = dev_upload(&g->d_col, h.col, tot))) return rc;
     if ((rc = dev_upload(&g->d_pos, h.pos_of_ext, tot))) return rc;
+    if (h.geo.n_seg == 1) {             // the whole graph: the last launch of a converge writes slot order itself
+        std::vector<uint32_t> peer(h.geo.rows_cap, 0xFFFFFFFFu);
+        for (uint32_t i = 0; i < h.n; ++i) {
+            const uint32_t p = h.pos_of_ext[i];
+            if (p == 0xFFFFFFFFu) continue;
+            if (p >= h.geo.rows_cap) { set_error("internal: position beyond the rows"); return ET_E_OUT_OF_RANGE; }
+            peer[p] = i;
+        }
+        if ((rc = dev_upload(&g->d_peer, peer, tot))) return rc;
+        g->no_fused_run = getenv("ET_NO_FUSED_RUN") != nullptr;
+    }
     const size_t slots = (size_t)h.n_steps * 64;
     const size_t vec_len = h.geo.vec_len;                                  // entries of the vectors the steps take
     const size_t stride = h.geo.seg_stride(), full_len = (size_t)h.geo.n_seg * stride;
@@ -1453,7 +1526,11 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
             if ((rc = dev_alloc(&g->vx[i], vec_len, tot))) return rc;
             HIP_TRY(hipMemset(g->vx[i], 0, vec_len * sizeof(double)));
         }
-        if ((h.geo.n_seg == 1 && (rc = dev_alloc(&g->out_f64, h.n, tot))) || (rc = dev_alloc(&g->d_res_part, (size_t)STATS_RING * g->n_f64_parts, tot)) ||
+        if (h.geo.n_seg == 1) {         // slots without a member read zero and are never written again
+            if ((rc = dev_alloc(&g->out_f64, h.n, tot))) return rc;
+            HIP_TRY(hipMemset(g->out_f64, 0, (size_t)h.n * sizeof(double)));
+        }
+        if ((rc = dev_alloc(&g->d_res_part, (size_t)STATS_RING * g->n_f64_parts, tot)) ||
             (rc = dev_alloc(&g->d_sum_part, (size_t)STATS_RING * g->n_f64_parts, tot))) return rc;
     }
     if (g->variants & ET_VARIANT_FR) {
@@ -1503,7 +1580,11 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
             else hipLaunchKernelGGL(k_scale_288, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, 0, g->d_scale_fr, g->d_fb_scale, stride);
             HIP_TRY(hipDeviceSynchronize());
         }
-        if ((h.geo.n_seg == 1 && (rc = dev_alloc(&g->out_fr, (size_t)h.n * 2, tot))) || (rc = dev_alloc(&g->d_frsum_part, (size_t)STATS_RING * g->n_fr_parts * 2, tot)) ||
+        if (h.geo.n_seg == 1) {
+            if ((rc = dev_alloc(&g->out_fr, (size_t)h.n * 2, tot))) return rc;
+            HIP_TRY(hipMemset(g->out_fr, 0, (size_t)h.n * 32));
+        }
+        if ((rc = dev_alloc(&g->d_frsum_part, (size_t)STATS_RING * g->n_fr_parts * 2, tot)) ||
             (rc = dev_alloc(&g->d_chg_part, (size_t)STATS_RING * g->n_fr_parts, tot))) return rc;
     }
     if ((rc = dev_alloc(&g->d_stat_out, 64, tot))) return rc;
@@ -1579,7 +1660,8 @@ static void launch_f64(const StepArgsF64B& a, unsigned blocks, size_t lds, hipSt
     if (a.alpha != 0.0) hipLaunchKernelGGL((k_step_f64_blocked<VT, true, PACKED, PHASED>), dim3(blocks), dim3(1024), lds, st, a);
     else hipLaunchKernelGGL((k_step_f64_blocked<VT, false, PACKED, PHASED>), dim3(blocks), dim3(1024), lds, st, a);
 }
-int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, uint32_t flags, hipStream_t st, int phase) {
+int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, uint32_t flags, hipStream_t st, int phase,
+                          const StepExtra* ex) {
     if (!(variants & ET_VARIANT_F64)) { set_error("graph was built without the f64 variant"); return ET_E_UNSUPPORTED; }
     if (x == y) { set_error("step needs distinct input and output vectors"); return ET_E_INVALID_ARG; }
     if (alpha != 0.0 && !pretrust) { set_error("alpha != 0 needs a pre-trust vector"); return ET_E_INVALID_ARG; }
@@ -1592,6 +1674,9 @@ int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double
     a.geo = geo; a.inv_nm1 = inv_nm1; a.alpha = alpha; a.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u;
     a.phase_ptr = d_bk_phase; a.acc_g = d_f64_acc; a.n_phases = geo.n_chunks;
     a.bar_period = f64_bar_period; a.bar_first_256 = f64_bar_first_256;
+    a.first_step = ex && ex->first_step ? 1u : 0u; a.initial = ex ? ex->initial64 : 0.0;
+    a.out = ex && a.final_step ? static_cast<double*>(ex->out) : nullptr; a.peer = d_peer;
+    if (a.out && (!d_peer || geo.n_chunks != 1)) { set_error("internal: scores in slot order need the whole graph in one launch"); return ET_E_UNSUPPORTED; }
     if (phase >= (int)geo.n_chunks) { set_error("no such phase"); return ET_E_OUT_OF_RANGE; }
     const size_t lds = (size_t)geo.f64_rb * sizeof(double);
     // phase < 0: the whole iteration, as n_chunks launches one after the other
@@ -1610,7 +1695,7 @@ int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double
     HIP_TRY(hipGetLastError());
     return ET_OK;
 }
-int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t flags, hipStream_t st, int phase) {
+int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t flags, hipStream_t st, int phase, const StepExtra* ex) {
     if (!(variants & ET_VARIANT_FR)) { set_error("graph was built without the Fr variant"); return ET_E_UNSUPPORTED; }
     if (x == y) { set_error("step needs distinct input and output vectors"); return ET_E_INVALID_ARG; }
     if (fr_blocked) {
@@ -1623,6 +1708,10 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
         fb.inv_nm1_w576 = to_u256((Fr::from_raw(inv_nm1_w) * Fr::one().pow2k(288)).to_raw());
         fb.phase_ptr = d_fb_phase; fb.acc_g = d_fr_acc; fb.n_phases = geo.n_chunks;
         fb.bar_period = fr_bar_period; fb.bar_first_256 = fr_bar_first_256;
+        fb.count_changes = (flags & ET_STEP_NO_CHANGED) ? 0u : 1u;
+        fb.first_step = ex && ex->first_step ? 1u : 0u; fb.initial = to_u256(ex ? ex->initial_fr : FrRaw{});
+        fb.out = ex && fb.final_step ? static_cast<uint4*>(ex->out) : nullptr; fb.peer = d_peer;
+        if (fb.out && (!d_peer || geo.n_chunks != 1)) { set_error("internal: scores in slot order need the whole graph in one launch"); return ET_E_UNSUPPORTED; }
         if (phase >= (int)geo.n_chunks) { set_error("no such phase"); return ET_E_OUT_OF_RANGE; }
         for (uint32_t q = phase < 0 ? 0u : (uint32_t)phase; q < (phase < 0 ? geo.n_chunks : (uint32_t)phase + 1); ++q) {
             fb.phase = q;
@@ -1643,6 +1732,7 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
         return ET_OK;
     }
     if (phase > 0) { set_error("no such phase"); return ET_E_OUT_OF_RANGE; }   // n_chunks is 1 without the blocked sweep
+    if (ex) { set_error("internal: the row-per-lane kernels take a vector written by init"); return ET_E_UNSUPPORTED; }
     StepArgsFr a;
     a.work = d_work; a.slices = d_slices; a.col = d_col; a.wlo = d_wlo; a.whi = d_whi; a.val = d_val; a.x = x; a.y = y;
     a.own = own_fr; a.scale = d_scale_fr;
@@ -1769,10 +1859,28 @@ int DeviceGraph::event_times(float* total_ms, uint32_t* pairs) {
     return ET_OK;
 }
 
+// A whole converge.  The blocked sweeps take the first iteration's input from a vector that is written once and kept
+// while the initial score stays the same (no init launch per converge), and their last launch writes the scores in slot
+// order (no un-permutation launch); slots without a member are zero from the allocation on and never written.
 int DeviceGraph::run_f64(uint32_t iters, double initial, double alpha, hipStream_t st, bool record) {
     if (geo.n_seg != 1) { set_error("run needs the whole graph on one GPU"); return ET_E_UNSUPPORTED; }
-    int rc = init_f64(initial, vx[0], st, iters == 0);
-    if (rc) return rc;
+    const bool fused = iters > 0 && geo.n_chunks == 1 && d_peer && !no_fused_run;
+    int rc;
+    if (!fused) {
+        if ((rc = init_f64(initial, vx[0], st, iters == 0))) return rc;
+    } else if (!x0_64 || x0_64_initial != initial) {
+        if (!x0_64) {
+            uint64_t got = 0;
+            if ((rc = dev_alloc(&x0_64, vec_len, got))) return rc;
+            device_bytes += got;
+        }
+        x0_64_initial = std::nan("");
+        const double d0 = (double)n_dangling_local * initial;
+        hipLaunchKernelGGL(k_init_f64, dim3((geo.seg_stride() + 255) / 256), dim3(256), 0, st, geo, initial, d0, x0_64,
+                           (double*)nullptr, raw ? d_scale64 : nullptr);
+        HIP_TRY(hipGetLastError());
+        x0_64_initial = initial;
+    }
     const double* pre = nullptr;
     if (alpha != 0.0) {
         // default pre-trust: the initial vector (plain scores, position order)
@@ -1784,23 +1892,60 @@ int DeviceGraph::run_f64(uint32_t iters, double initial, double alpha, hipStream
         if ((rc = init_f64(initial, d_pretrust, st, true))) return rc;
         pre = d_pretrust;
     }
+    StepExtra ex;
+    ex.initial64 = initial;
+    ex.out = out_f64;
     if (record && (rc = record_begin(st))) return rc;
-    for (uint32_t it = 0; it < iters; ++it)
-        if ((rc = step_f64(vx[it & 1], vx[(it + 1) & 1], it, alpha, pre, it + 1 == iters ? ET_STEP_FINAL : 0u, st))) return rc;
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint32_t flags = it + 1 == iters ? ET_STEP_FINAL : 0u;
+        if (!fused) rc = step_f64(vx[it & 1], vx[(it + 1) & 1], it, alpha, pre, flags, st);
+        else {
+            ex.first_step = it == 0;
+            rc = step_f64(it == 0 ? x0_64 : vx[it & 1], vx[(it + 1) & 1], it, alpha, pre, flags, st, -1, &ex);
+        }
+        if (rc) return rc;
+    }
     if (record && (rc = record_end(st))) return rc;
-    if ((rc = unpermute_f64(vx[iters & 1], out_f64, st))) return rc;
+    if (!fused && (rc = unpermute_f64(vx[iters & 1], out_f64, st))) return rc;
     last_iters = iters;
     return ET_OK;
 }
 int DeviceGraph::run_fr(uint32_t iters, uint64_t lo, uint64_t hi, hipStream_t st, bool record) {
     if (geo.n_seg != 1) { set_error("run needs the whole graph on one GPU"); return ET_E_UNSUPPORTED; }
-    int rc = init_fr(lo, hi, fx[0], st, iters == 0);
-    if (rc) return rc;
+    const bool fused = iters > 0 && geo.n_chunks == 1 && fr_blocked && raw && d_peer && !no_fused_run;
+    int rc;
+    const Fr init = Fr::from_u128(lo, hi);
+    if (!fused) {
+        if ((rc = init_fr(lo, hi, fx[0], st, iters == 0))) return rc;
+    } else if (!x0_fr || !x0_fr_valid || x0_fr_lo != lo || x0_fr_hi != hi) {
+        if (!x0_fr) {
+            uint64_t got = 0;
+            if ((rc = dev_alloc(&x0_fr, vec_len * 2, got))) return rc;
+            device_bytes += got;
+        }
+        x0_fr_valid = false;
+        const Fr d0 = init * Fr::from_u64(n_dangling_local);
+        hipLaunchKernelGGL(k_init_fr, dim3((geo.seg_stride() + 255) / 256), dim3(256), 0, st, geo, to_u256(init.to_raw()), to_u256(d0.to_raw()),
+                           x0_fr, (uint4*)nullptr, d_scale_fr);
+        HIP_TRY(hipGetLastError());
+        x0_fr_lo = lo; x0_fr_hi = hi; x0_fr_valid = true;
+    }
+    StepExtra ex;
+    ex.initial_fr = init.to_raw();
+    ex.out = out_fr;
     if (record && (rc = record_begin(st))) return rc;
-    for (uint32_t it = 0; it < iters; ++it)
-        if ((rc = step_fr(fx[it & 1], fx[(it + 1) & 1], it, it + 1 == iters ? ET_STEP_FINAL : 0u, st))) return rc;
+    for (uint32_t it = 0; it < iters; ++it) {
+        // the number of changed rows is asked of the last step only (what a converge reports)
+        const uint32_t flags = it + 1 == iters ? ET_STEP_FINAL : ET_STEP_NO_CHANGED;
+        if (!fused) rc = step_fr(fx[it & 1], fx[(it + 1) & 1], it, flags, st);
+        else {
+            ex.first_step = it == 0;
+            rc = step_fr(it == 0 ? x0_fr : fx[it & 1], fx[(it + 1) & 1], it, flags, st, -1, &ex);
+        }
+        if (rc) return rc;
+    }
     if (record && (rc = record_end(st))) return rc;
-    if ((rc = unpermute_fr(fx[iters & 1], out_fr, st))) return rc;
+    if (!fused && (rc = unpermute_fr(fx[iters & 1], out_fr, st))) return rc;
     last_iters = iters;
     return ET_OK;
 }

@@ -97,6 +97,15 @@ struct DeviceGraph {
     double* out_f64 = nullptr;
     uint4* out_fr = nullptr;
     double* d_pretrust = nullptr;
+    // a whole converge on one GPU (run_*): slot of the peer at every position, and the first iteration's input vector,
+    // kept from converge to converge while the initial score is the same
+    uint32_t* d_peer = nullptr;
+    double* x0_64 = nullptr;
+    double x0_64_initial = 0.0;
+    uint4* x0_fr = nullptr;
+    uint64_t x0_fr_lo = 0, x0_fr_hi = 0;
+    bool x0_fr_valid = false;
+    bool no_fused_run = false;        // ET_NO_FUSED_RUN=1: init and un-permutation as launches of their own
     // Gather vector (geo.compact): after a step this share packs, for every other share c, the entries of its own block that
     // c cites followed by its partial sums -- send_cnt[c] entries at send_off[c] of the pack buffer, picked by d_send_idx --
     // and receives recv_cnt[p] entries from share p at recv_off[p] of the vector.  Position order: every share sends its whole
@@ -116,9 +125,18 @@ struct DeviceGraph {
     // plain = true writes plain scores whatever the form (a vector that is read back, not iterated)
     int init_f64(double initial, double* x, hipStream_t st, bool plain = false);
     int init_fr(uint64_t lo, uint64_t hi, uint4* x, hipStream_t st, bool plain = false);
+    // What run_* tells the blocked sweeps beyond the public flags: the step reads the kept initial vector (the dangling
+    // rows' plain scores are then `initial`, not what the last converge left), and the final step writes slot order to out.
+    struct StepExtra {
+        bool first_step = false;
+        double initial64 = 0.0;
+        FrRaw initial_fr{};
+        void* out = nullptr;
+    };
     // phase: which of the geo.n_chunks launches of the iteration to enqueue; -1 = all of them, one after the other
-    int step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, uint32_t flags, hipStream_t st, int phase = -1);
-    int step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t flags, hipStream_t st, int phase = -1);
+    int step_f64(const double* x, double* y, uint32_t iteration, double alpha, const double* pretrust, uint32_t flags, hipStream_t st, int phase = -1,
+                 const StepExtra* ex = nullptr);
+    int step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t flags, hipStream_t st, int phase = -1, const StepExtra* ex = nullptr);
     int unpermute_f64(const double* x, double* out, hipStream_t st);
     int unpermute_fr(const uint4* x, uint4* out, hipStream_t st);
     int stats_f64(uint32_t iteration, hipStream_t st, et_iter_stats* out);

@@ -192,6 +192,38 @@ def test_iteration_counts_including_zero(iters):
     assert np.array_equal(g.converge_fr(iters, 1000), exp)
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_converges_in_a_row_with_other_initial_scores_and_iteration_counts(fused, monkeypatch):
+    # A whole converge keeps its first input vector between calls and writes slot order from its last launch
+    # (ET_NO_FUSED_RUN=1: init and un-permutation as launches of their own).  Peers without opinions keep a plain score
+    # inside the graph object that the previous converge left behind, and empty slots must read zero every time.
+    if not fused:
+        monkeypatch.setenv("ET_NO_FUSED_RUN", "1")
+    rng = np.random.default_rng(77)
+    n = 6000
+    member, frm, to, val = random_graph(rng, n, 9, 0.07, 0.2, 255, hub=True)
+    g = pa.Graph(n, frm, to, value_u32=val, member=member)
+    for iters, initial in ((20, 1000), (20, 1000), (3, 777), (1, 777), (20, 1000), (0, 5), (2, 5)):
+        rc, exp, _, _ = c_oracle.sparse_converge_fr(n, member, frm, to, value_u32=val, num_iter=iters, initial=initial)
+        assert rc == 0
+        got = g.converge_fr(iters, initial)
+        assert np.array_equal(got, exp), (iters, initial)
+        assert all(v == 0 for v, m in zip(pa.fr_ints_from_bytes(got), member) if not m)
+        rc, _e, eld, eres, _, _ = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=iters, initial=float(initial), want_ld=True)
+        assert rc == 0
+        o64, res = g.converge_f64(iters, float(initial))
+        assert rel_l1(o64, eld) <= F64_TOL, (iters, initial)
+        assert np.all(o64[member == 0] == 0.0)
+        if iters:
+            assert abs(res - eres) <= 1e-6 * max(1.0, abs(eres))
+    # damping with the default pre-trust (the initial scores) goes through the same launches
+    rc, _e, eld, _r, _, _ = c_oracle.sparse_converge_f64(n, member, frm, to, value_u32=val, num_iter=20, initial=1000.0, alpha=0.15,
+                                                         pretrust=1000.0 * member, want_ld=True)
+    assert rc == 0
+    o64, _ = g.converge_f64(20, 1000.0, alpha=0.15)
+    assert rel_l1(o64, eld) <= F64_TOL
+
+
 def test_no_attestations_at_all():
     # every member is dangling: each gives 1 to every other member (native.rs:263-278), scores stay put
     n = 70
