@@ -132,6 +132,8 @@ pub struct et_exchange_info {
     pub send_off: [u32; 8],
     pub send_count: [u32; 8],
     pub send_total: u64,
+    pub self_off: u32,
+    pub self_count: u32,
 }
 
 #[repr(C)]
@@ -180,6 +182,7 @@ pub struct et_sweep_stats {
     pub line_fills: u64,
     pub line_fills_most: u64,
     pub chunk_span_most: u64,
+    pub xcd_line_fills: u64,
 }
 
 #[repr(C)]
@@ -272,8 +275,8 @@ extern "C" {
     pub fn et_graph_exchange_get(g: *const et_graph, out: *mut et_exchange_info) -> c_int;
     pub fn et_plan_exchange_get(p: *const et_plan, out: *mut et_exchange_info, need: *mut *const u32,
                                 send: *mut *const u32) -> c_int;
-    pub fn et_graph_pack_fr_async(g: *mut et_graph, y: *const c_void, send: *mut c_void, stream: *mut c_void) -> c_int;
-    pub fn et_graph_pack_f64_async(g: *mut et_graph, y: *const c_void, send: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn et_graph_pack_fr_async(g: *mut et_graph, y: *mut c_void, send: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn et_graph_pack_f64_async(g: *mut et_graph, y: *mut c_void, send: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn et_graph_unpermute_fr_async(g: *mut et_graph, x: *const c_void, out_slots: *mut c_void,
                                        stream: *mut c_void) -> c_int;
     pub fn et_graph_unpermute_f64_async(g: *mut et_graph, x: *const c_void, out_slots: *mut c_void,

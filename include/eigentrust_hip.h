@@ -224,6 +224,7 @@ typedef struct {
     uint64_t edges, edges_most;            /* all workgroups, the busiest one */
     uint64_t line_fills, line_fills_most;
     uint64_t chunk_span_most;              /* widest range of positions 64 consecutive edges of a list span */
+    uint64_t xcd_line_fills;               /* distinct (line, XCD) pairs, workgroup b on XCD b mod 8: the lines the eight L2s pull */
 } et_sweep_stats;
 int et_plan_sweep_stats(const et_plan *p, int variant, et_sweep_stats *out);
 /* Uploads a plan (what et_graph_build does after planning). */
@@ -281,12 +282,16 @@ int et_graph_step_f64_phase_async(et_graph *g, const void *x, void *y, uint32_t 
  * mass: own_len entries at own_off) and the shares exchange before the next step.
  *   gather == 0 (one share; field-valued opinions; a chunked exchange; ET_BUILD_FULL_VECTOR): vectors hold every
  *     share's block in position order, own_off = seg * own_len, and the exchange is an in-place all-gather of blocks.
- *   gather == 1 (several shares, integer opinions): a share's vectors hold its own block first (own_off = 0) and then,
- *     for every other share p in ascending order, only the entries of p's rows that this share's rows cite, followed by
- *     p's partial sums: recv_count[p] entries at recv_off[p].  After a step, et_graph_pack_*_async copies what every
- *     other share c cites out of the own block of y into a send buffer of send_total entries (send_count[c] entries at
- *     send_off[c]); an all-to-all (send block c to share c, receive block p at recv_off[p] of y) completes y.  The
- *     16M-peer benchmark graph on 8 shares: 9.1M of 16.8M entries per share, i.e. 0.54 of the all-gather's bytes.
+ *   gather == 1 (several shares, integer opinions): a share's vectors hold its own block first (own_off = 0), then the
+ *     entries of its OWN rows that its rows cite (self_count entries at self_off, in the order its sweeps want them), and
+ *     then, for every other share p in ascending order, only the entries of p's rows that this share's rows cite, followed
+ *     by p's partial sums: recv_count[p] entries at recv_off[p].  The sweeps gather from these blocks; the own block is what
+ *     a step writes.  After a step, et_graph_pack_*_async copies what every other share c cites out of the own block of y
+ *     into a send buffer of send_total entries (send_count[c] entries at send_off[c]) and the share's own cited entries
+ *     into their block of y; an all-to-all (send block c to share c, receive block p at recv_off[p] of y: one contiguous
+ *     range in share order) completes y.  The pack also follows et_graph_init_*.
+ *     The 16M-peer benchmark graph on 8 shares: 8.0M of 14.7M entries received per share and iteration, i.e. 0.54 of the
+ *     all-gather's bytes.
  *     The LAST step's y holds plain scores of the own block only; the result in slot order needs the shares' own blocks
  *     all-gathered into a vector in position order (full_len entries, block p at p * own_len) for et_graph_unpermute_*. */
 typedef struct {
@@ -297,14 +302,17 @@ typedef struct {
     uint32_t recv_off[8], recv_count[8];   /* entries; zero for the share itself                         */
     uint32_t send_off[8], send_count[8];   /* gather == 0: every share is sent the whole own block        */
     uint64_t send_total;                   /* entries of the pack buffer                                   */
+    uint32_t self_off, self_count;         /* gather == 1: the block of the share's own cited entries      */
 } et_exchange_info;
 int et_graph_exchange_get(const et_graph *g, et_exchange_info *out);
-/* Fills `send` (send_total entries of 32 / 8 bytes) from the own block of y.  gather == 0: a copy of the own block. */
-int et_graph_pack_fr_async(et_graph *g, const void *y, void *send, void *stream);
-int et_graph_pack_f64_async(et_graph *g, const void *y, void *send, void *stream);
+/* Fills `send` (send_total entries of 32 / 8 bytes) from the own block of y and, with a gather vector, the block of the
+ * share's own cited entries inside y.  gather == 0: a copy of the own block. */
+int et_graph_pack_fr_async(et_graph *g, void *y, void *send, void *stream);
+int et_graph_pack_f64_async(et_graph *g, void *y, void *send, void *stream);
 /* The exchange tables of a host-side plan and, with a gather vector, the lists behind them: need[p] = the local rows of
- * share p this share cites (recv_count[p] - nd_cap entries, ascending), send[c] = the local rows of this share that
- * share c cites (send_count[c] - nd_cap entries).  need / send: arrays of 8 pointers to fill, or NULL. */
+ * share p this share cites (recv_count[p] - nd_cap entries; p == seg: self_count entries), in the order of their block,
+ * send[c] = the local rows of this share that share c cites (send_count[c] - nd_cap entries).  need / send: arrays of 8
+ * pointers to fill, or NULL. */
 int et_plan_exchange_get(const et_plan *p, et_exchange_info *out, const uint32_t **need, const uint32_t **send);
 
 /* Position order -> slot order (device to device): x has full_len entries in position order, out has n entries. */

@@ -70,7 +70,8 @@ class EtExchangeInfo(C.Structure):
                 ("vec_len", C.c_uint64), ("full_len", C.c_uint64),
                 ("recv_off", C.c_uint32 * 8), ("recv_count", C.c_uint32 * 8),
                 ("send_off", C.c_uint32 * 8), ("send_count", C.c_uint32 * 8),
-                ("send_total", C.c_uint64)]
+                ("send_total", C.c_uint64),
+                ("self_off", C.c_uint32), ("self_count", C.c_uint32)]
 
 
 class EtSliceDesc(C.Structure):
@@ -92,7 +93,7 @@ class EtPlanArrays(C.Structure):
 
 class EtSweepStats(C.Structure):
     _fields_ = [("blocks", C.c_uint32), ("clustered", C.c_uint32), ("edges", C.c_uint64), ("edges_most", C.c_uint64),
-                ("line_fills", C.c_uint64), ("line_fills_most", C.c_uint64), ("chunk_span_most", C.c_uint64)]
+                ("line_fills", C.c_uint64), ("line_fills_most", C.c_uint64), ("chunk_span_most", C.c_uint64), ("xcd_line_fills", C.c_uint64)]
 
 
 class EtScore(C.Structure):

@@ -609,11 +609,13 @@ namespace {
 // order of the source's visit key (position; piece by piece with a chunked exchange) in T contiguous chunks of the order.
 // visit(local row, source code (segment << 29 | local row), handle); the handle fetches the edge's value.
 
-// Gather vectors: the order a share asks for the entries of another share's rows.
+// Gather vectors: the order of a share's blocks of cited entries (the other shares' rows, and its own rows' entries copied
+// out of the own block by the pack).
 //
 // A blocked sweep is bound by the 128-byte lines a workgroup's gathers pull into its L1, and a source cited a few times
-// costs one line per edge when its line-mates are gathered by other workgroups.  The entries of ANOTHER share's rows
-// have no place of their own in this share's vector, so the share puts them where its workgroups want them: the
+// costs one line per edge when its line-mates are gathered by other workgroups.  The cited entries have no place of their
+// own in this share's vector (the own block, in row order, is only written and packed from), so the share puts them where
+// its workgroups want them: the
 // sources its rows cite `hot` times or more keep the front of their block, in position order (most-attesting first:
 // nearly every workgroup gathers them anyway), and the others follow grouped by the workgroup that cites them most,
 // then by the workgroup that cites them next, so that a line of sixteen (four) entries serves one workgroup sixteen
@@ -622,6 +624,10 @@ struct CitedSource { uint32_t local, edges, wg1, wg2; };
 static void order_cited_sources(std::vector<CitedSource>& src, uint32_t hot, uint32_t fold) {
     // workgroups b and b + fold of the sweep with more workgroups are ONE workgroup of the other sweep: side by side
     auto wg_key = [&](uint32_t w) -> uint64_t { return w == 0xFFFFFFFFu ? 0xFFFFFFFFull : (uint64_t)(w % fold) * 64 + w / fold; };
+    // (Tried on the share of eight of the 16M-peer graph: the cold sources grouped first by the SET of XCDs whose workgroups
+    // cite them halves the lines the eight L2s pull, 2.3M -> 1.1M, for 4 % more lines into the L1s, and the launch gets 5 %
+    // slower: the L1 fills are what the sweeps wait for.  Sources two workgroups cite kept apart from those three or more
+    // cite: no difference.)
     std::sort(src.begin(), src.end(), [&](const CitedSource& a, const CitedSource& b) {
         const bool ha = a.edges >= hot, hb = b.edges >= hot;
         if (ha != hb) return ha;
@@ -699,11 +705,9 @@ struct AttesterWalk {
             // ranks ascend with the local row inside every share, so the lists come out ascending
             for (uint32_t r = 0; r < n_active; ++r) {
                 const uint32_t f = pc.order[r], pos = g.pos_of_ext[f], p = pos / stride, local = pos % stride;
-                if (p == geo.seg) {
+                if (p == geo.seg)
                     for (uint32_t c = 0; c < geo.n_seg; ++c) if (wanted[f] >> c & 1) g.send[c].push_back(local);
-                } else if (cited[f]) {
-                    g.need[p].push_back(local);
-                }
+                if (cited[f]) g.need[p].push_back(local);      // the share's own rows too: their block of cited entries
             }
             g.send_known = true;
             uint32_t counts[8];
@@ -711,9 +715,8 @@ struct AttesterWalk {
             geo.set_gather_blocks(counts, g.blk_off);
             std::vector<uint32_t> at(8, 0);
             for (uint32_t r = 0; r < n_active; ++r) {
-                const uint32_t f = pc.order[r], pos = g.pos_of_ext[f], p = pos / stride;
-                if (p == geo.seg) code_of_ext[f] = pos % stride;
-                else if (cited[f]) code_of_ext[f] = g.blk_off[p] + at[p]++;
+                const uint32_t f = pc.order[r], p = g.pos_of_ext[f] / stride;
+                if (cited[f]) code_of_ext[f] = g.blk_off[p] + at[p]++;
             }
             for (uint32_t r = 0; r < n_active; ++r) if (cited[pc.order[r]]) by_pos.push_back(pc.order[r]);
         } else {
@@ -765,13 +768,9 @@ struct AttesterWalk {
             }
         });
         std::vector<std::vector<CitedSource>> per(geo.n_seg);
-        for (uint32_t i = 0; i < n_walk; ++i) {
-            const uint32_t p = g.pos_of_ext[by_pos[i]] / stride;
-            if (p != geo.seg) per[p].push_back(cs[i]);
-        }
+        for (uint32_t i = 0; i < n_walk; ++i) per[g.pos_of_ext[by_pos[i]] / stride].push_back(cs[i]);
         std::vector<uint32_t> ext_of_local;
         for (uint32_t p = 0; p < geo.n_seg; ++p) {
-            if (p == geo.seg) continue;
             ext_of_local.assign(stride, 0xFFFFFFFFu);
             for (uint32_t i = 0; i < n_walk; ++i) {
                 const uint32_t pos = g.pos_of_ext[by_pos[i]];
@@ -826,8 +825,8 @@ struct RecordWalk {
     RecordWalk(HostGraph& g, unsigned T_, const std::vector<uint32_t>& src_in, const std::vector<uint32_t>& row_in,
                const std::vector<uint32_t>& val_in) : geo(g.geo), T(T_), count(src_in.size()) {
         const uint32_t stride = geo.seg_stride();
-        // visit key: position (piece by piece with a chunked exchange); gather vector: the share's own block first, then
-        // the other shares' in ascending order, local rows ascending inside a block
+        // visit key: position (piece by piece with a chunked exchange); gather vector: the block of the share's own cited
+        // rows first, then the other shares' in ascending order, local rows ascending inside a block
         auto block_rank = [&](uint32_t p) -> uint32_t { return !geo.compact ? p : (p == geo.seg ? 0u : (p < geo.seg ? p + 1 : p)); };
         auto key_of = [&](uint32_t code) -> uint64_t {
             const uint32_t local = code & COL_LOCAL_MASK;
@@ -880,13 +879,13 @@ struct RecordWalk {
             });
             return;
         }
-        // gather vector: the distinct sources of every other share, ascending, are what this share needs from it
+        // gather vector: the distinct sources of every share (this one included), ascending, are what this share needs from it
         auto share_of_rank = [&](uint32_t br) -> uint32_t { return br == 0 ? geo.seg : (br <= geo.seg ? br - 1 : br); };
         for (uint32_t p = 0; p < 8; ++p) { g.need[p].clear(); }
         for (uint64_t k = 0; k < count; ++k) {
-            const uint32_t v = (uint32_t)(buf[k].key & 0xFFFFFFFFull), br = v / stride;
-            if (br == 0 || (k && buf[k - 1].key == buf[k].key)) continue;
-            g.need[share_of_rank(br)].push_back(v % stride);
+            const uint32_t v = (uint32_t)(buf[k].key & 0xFFFFFFFFull);
+            if (k && buf[k - 1].key == buf[k].key) continue;
+            g.need[share_of_rank(v / stride)].push_back(v % stride);
         }
         uint32_t counts[8];
         for (uint32_t p = 0; p < 8; ++p) counts[p] = (uint32_t)g.need[p].size();
@@ -896,12 +895,8 @@ struct RecordWalk {
             uint64_t k = count * t / T;
             const uint64_t k1 = count * (t + 1) / T;
             while (k < k1) {
-                const uint32_t v = (uint32_t)(buf[k].key & 0xFFFFFFFFull), br = v / stride, local = v % stride;
-                uint32_t code = local;
-                if (br != 0) {
-                    const uint32_t p = share_of_rank(br);
-                    code = g.blk_off[p] + (uint32_t)(std::lower_bound(g.need[p].begin(), g.need[p].end(), local) - g.need[p].begin());
-                }
+                const uint32_t v = (uint32_t)(buf[k].key & 0xFFFFFFFFull), p = share_of_rank(v / stride), local = v % stride;
+                const uint32_t code = g.blk_off[p] + (uint32_t)(std::lower_bound(g.need[p].begin(), g.need[p].end(), local) - g.need[p].begin());
                 const uint64_t key = buf[k].key;
                 for (; k < k1 && buf[k].key == key; ++k) src[k] = code;
             }
@@ -921,9 +916,9 @@ struct RecordWalk {
                 for (; k < count && src[k] == code; ++k) { box.add(wg_of_group[row[k] / BLOCK_GROUP]); ++edges; }
                 CitedSource c{0, edges, 0, 0};
                 box.take(code, c.wg1, c.wg2);
-                if (code < stride) continue;                                    // the share's own block keeps its order
-                uint32_t p = 0;
-                for (uint32_t q = 0; q < geo.n_seg; ++q) if (q != geo.seg && code >= g.blk_off[q]) p = q;   // blocks ascend with the share
+                uint32_t p = geo.n_seg;
+                for (uint32_t q = 0; q < geo.n_seg; ++q) if (code >= g.blk_off[q] && code - g.blk_off[q] < g.need[q].size()) p = q;
+                if (p == geo.n_seg) continue;                                   // cannot happen: every code lies in one block
                 c.local = g.need[p][code - g.blk_off[p]];
                 per[p].push_back(c);
             }
@@ -932,7 +927,6 @@ struct RecordWalk {
         for (uint32_t i = 0; i < geo.vec_len; ++i) remap[i] = i;
         std::vector<uint32_t> code_of_local;
         for (uint32_t p = 0; p < geo.n_seg; ++p) {
-            if (p == geo.seg) continue;
             code_of_local.assign(stride, 0xFFFFFFFFu);
             for (uint32_t j = 0; j < g.need[p].size(); ++j) code_of_local[g.need[p][j]] = g.blk_off[p] + j;
             order_cited_sources(per[p], hot, fold);
@@ -1174,10 +1168,10 @@ int fill_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned T,
         for (int exact = 0; exact < 2; ++exact) {
             const SweepStats ss = sweep_stats(g, exact != 0);
             if (ss.blocks)
-                fprintf(stderr, "[et build] %s sweep: %u workgroups, %llu edges (most %llu, mean %.1f), %llu line fills (most %llu, mean %.1f), clustered %u, widest 64-edge chunk %llu positions\n",
+                fprintf(stderr, "[et build] %s sweep: %u workgroups, %llu edges (most %llu, mean %.1f), %llu line fills (most %llu, mean %.1f), clustered %u, widest 64-edge chunk %llu positions, %llu lines over the eight L2s\n",
                         exact ? "exact" : "f64", ss.blocks, (unsigned long long)ss.edges, (unsigned long long)ss.edges_most, (double)ss.edges / ss.blocks,
                         (unsigned long long)ss.line_fills, (unsigned long long)ss.line_fills_most, (double)ss.line_fills / ss.blocks, ss.clustered,
-                        (unsigned long long)ss.chunk_span_most);
+                        (unsigned long long)ss.chunk_span_most, (unsigned long long)ss.xcd_line_fills);
         }
     }
     if (geo.n_chunks > 1) {
@@ -1341,9 +1335,14 @@ SweepStats sweep_stats(const HostGraph& g, bool exact) {
     ss.blocks = B;
     ss.clustered = g.hint_blocks != 0 && g.hint_blocks % B == 0 && !g.grp_hint.empty();
     ss.edges = ptr[B];
+    // which of the eight L2s pull each line of the vector (workgroup b runs on XCD b mod 8)
+    std::vector<uint8_t> xcds_of_line((((size_t)g.geo.n_seg * g.geo.seg_stride() + g.geo.vec_len) >> shift) + 1, 0);
     for (uint32_t b = 0; b < B; ++b) {
         uint64_t c = 0;
-        for (uint64_t k = ptr[b]; k < ptr[b + 1]; ++k) c += k == ptr[b] || (col[k] >> shift) != (col[k - 1] >> shift);
+        for (uint64_t k = ptr[b]; k < ptr[b + 1]; ++k) {
+            c += k == ptr[b] || (col[k] >> shift) != (col[k - 1] >> shift);
+            xcds_of_line[g.geo.pos_of_col(col[k]) >> shift] |= (uint8_t)(1u << (b % 8));
+        }
         // widest range of positions that 64 consecutive edges of a list span (the packed edge records hold a 16-bit offset)
         for (uint64_t k = ptr[b]; k < ptr[b + 1]; k += 64) {
             const uint64_t last = std::min<uint64_t>(k + 63, ptr[b + 1] - 1);
@@ -1353,6 +1352,7 @@ SweepStats sweep_stats(const HostGraph& g, bool exact) {
         ss.line_fills_most = std::max(ss.line_fills_most, c);
         ss.edges_most = std::max(ss.edges_most, ptr[b + 1] - ptr[b]);
     }
+    for (uint8_t m : xcds_of_line) ss.xcd_line_fills += (uint64_t)__builtin_popcount(m);
     return ss;
 }
 

@@ -164,7 +164,7 @@ int filter_edges(const BuildInput& in, PlanCommon& pc, RowSums& sums, PeerStats&
 
 // Lines of the vector one launch of a blocked sweep pulls into the L1s: distinct (workgroup, 128-byte line) pairs of the
 // sorted per-workgroup lists (f64: 16 entries per line; exact: 4).  blocks = 0 when the plan holds no such lists.
-struct SweepStats { uint32_t blocks = 0, clustered = 0; uint64_t edges = 0, edges_most = 0, line_fills = 0, line_fills_most = 0, chunk_span_most = 0; };
+struct SweepStats { uint32_t blocks = 0, clustered = 0; uint64_t edges = 0, edges_most = 0, line_fills = 0, line_fills_most = 0, chunk_span_most = 0, xcd_line_fills = 0; };
 SweepStats sweep_stats(const HostGraph& g, bool exact);
 
 // host threads for the scatter passes over the edges (the GPU boxes give a process 16 CPUs)

@@ -172,6 +172,7 @@ int et_plan_sweep_stats(const et_plan* p, int variant, et_sweep_stats* out) {
     out->edges = ss.edges; out->edges_most = ss.edges_most;
     out->line_fills = ss.line_fills; out->line_fills_most = ss.line_fills_most;
     out->chunk_span_most = ss.chunk_span_most;
+    out->xcd_line_fills = ss.xcd_line_fills;
     return ET_OK;
 }
 int et_graph_from_plan(const et_plan* p, const et_build_opts* opts, et_graph** out) {
@@ -229,6 +230,7 @@ int et_graph_exchange_get(const et_graph* g, et_exchange_info* out) {
         out->send_off[c] = d->send_off[c]; out->send_count[c] = d->send_cnt[c];
     }
     out->send_total = d->send_total;
+    out->self_off = d->self_off; out->self_count = d->self_cnt;
     return ET_OK;
 }
 int et_plan_exchange_get(const et_plan* p, et_exchange_info* out, const uint32_t** need, const uint32_t** send) {
@@ -240,7 +242,14 @@ int et_plan_exchange_get(const et_plan* p, et_exchange_info* out, const uint32_t
     for (uint32_t c = 0; c < 8; ++c) {
         if (need) need[c] = nullptr;
         if (send) send[c] = nullptr;
-        if (c >= geo.n_seg || c == geo.seg) continue;
+        if (c >= geo.n_seg) continue;
+        if (c == geo.seg) {           // the share's own cited rows: nothing travels, the block is filled by the pack
+            if (geo.compact) {
+                out->self_off = h.blk_off[c]; out->self_count = (uint32_t)h.need[c].size();
+                if (need) need[c] = h.need[c].data();
+            }
+            continue;
+        }
         if (geo.compact) {
             out->recv_off[c] = h.blk_off[c]; out->recv_count[c] = (uint32_t)h.need[c].size() + geo.nd_cap;
             out->send_off[c] = at; out->send_count[c] = (uint32_t)h.send[c].size() + geo.nd_cap;
@@ -256,12 +265,12 @@ int et_plan_exchange_get(const et_plan* p, et_exchange_info* out, const uint32_t
     out->send_total = at;
     return ET_OK;
 }
-int et_graph_pack_fr_async(et_graph* g, const void* y, void* send, void* stream) {
+int et_graph_pack_fr_async(et_graph* g, void* y, void* send, void* stream) {
     if (!g || !y || !send) return ET_E_INVALID_ARG;
     HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->pack(y, send, 32, (hipStream_t)stream);
 }
-int et_graph_pack_f64_async(et_graph* g, const void* y, void* send, void* stream) {
+int et_graph_pack_f64_async(et_graph* g, void* y, void* send, void* stream) {
     if (!g || !y || !send) return ET_E_INVALID_ARG;
     HIP_TRY_C(hipSetDevice(G(g)->device));
     return G(g)->pack(y, send, 8, (hipStream_t)stream);

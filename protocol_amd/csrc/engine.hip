@@ -259,7 +259,10 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
 
     const uint64_t e0 = PHASED ? a.phase_ptr[(size_t)b * (a.n_phases + 1) + a.phase] : a.bk_ptr[b];
     const uint64_t e1 = PHASED ? a.phase_ptr[(size_t)b * (a.n_phases + 1) + a.phase + 1] : a.bk_ptr[b + 1];
-    constexpr int U = 4;
+#ifndef ET_F64_U
+#define ET_F64_U 4
+#endif
+    constexpr int U = ET_F64_U;
     // Full batches of U * 1024 edges, the same number for every thread.  The hardware favours the
     // oldest wavefront of a workgroup, which lets it run far ahead of the youngest; a barrier every
     // second batch keeps all sixteen within one window of the source range.
@@ -1191,15 +1194,21 @@ __global__ void k_unpermute_fr(const uint32_t* __restrict__ pos, const uint4* __
     U256 v = p == 0xFFFFFFFFu ? u256_zero() : u256_load(x + 2 * (size_t)p);
     u256_store(out + 2 * (size_t)i, v);
 }
-// Gather vector: the entries of this share's own block that another share cites, in the order it asked for.
+// Gather vector: the entries of this share's own block that another share cites, in the order it asked for (n entries
+// picked by idx into the send buffer), and the entries the share's own rows cite (n_self entries picked by idx_self into
+// the share's own block of cited entries, which lies behind the own block in the same vector).
 // One thread per 8 bytes (f64) or per 16-byte half of a field element.
-__global__ void k_pack_f64(const double* __restrict__ own, const uint32_t* __restrict__ idx, double* __restrict__ out, uint32_t n) {
+__global__ void k_pack_f64(const double* own, const uint32_t* __restrict__ idx, double* __restrict__ out, uint32_t n,
+                           const uint32_t* __restrict__ idx_self, double* out_self, uint32_t n_self) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = own[idx[i]];
+    else if (i - n < n_self) out_self[i - n] = own[idx_self[i - n]];
 }
-__global__ void k_pack_fr(const uint4* __restrict__ own, const uint32_t* __restrict__ idx, uint4* __restrict__ out, uint32_t n) {
+__global__ void k_pack_fr(const uint4* own, const uint32_t* __restrict__ idx, uint4* __restrict__ out, uint32_t n,
+                          const uint32_t* __restrict__ idx_self, uint4* out_self, uint32_t n_self) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 2 * n) out[i] = own[2 * (size_t)idx[i >> 1] + (i & 1)];
+    else if (i - 2 * n < 2 * n_self) { const uint32_t j = i - 2 * n; out_self[j] = own[2 * (size_t)idx_self[j >> 1] + (j & 1)]; }
 }
 // a * b mod r through the same multiply-accumulate and reduction the step kernel uses:
 // (a * 2^576 * 2^-288) * b * 2^-288.  `c576` = 2^576 mod r.
@@ -1240,7 +1249,7 @@ static int dev_upload(T** p, const std::vector<T>& v, uint64_t& total) {
 DeviceGraph::~DeviceGraph() {
     if (device >= 0) (void)hipSetDevice(device);
     void* ptrs[] = {d_send_idx, d_fb_rec, d_fb_cbase, d_fb_cptr, d_bk_ptr, d_bk_grp, d_bk_col, d_bk_row, d_bk_w, d_bk_rec, d_bk_cbase, d_bk_cptr, d_fb_ptr, d_fb_grp, d_fb_col, d_fb_row, d_fb_val, d_work, d_slices, d_col, d_val, d_wlo, d_whi, d_pos, d_res_part, d_sum_part, d_frsum_part,
-                    d_chg_part, d_stat_out, d_bk_phase, d_fb_phase, d_f64_acc, d_fr_acc, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust, d_scale64, d_scale_fr, d_fb_scale, own64, own_fr, d_peer, x0_64, x0_fr};
+                    d_chg_part, d_stat_out, d_bk_phase, d_fb_phase, d_f64_acc, d_fr_acc, vx[0], vx[1], fx[0], fx[1], out_f64, out_fr, d_pretrust, d_scale64, d_scale_fr, d_fb_scale, own64, own_fr, d_peer, x0_64, x0_fr, d_self_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* e : ev_begin) (void)hipEventDestroy((hipEvent_t)e);
     for (void* e : ev_end) (void)hipEventDestroy((hipEvent_t)e);
@@ -1598,6 +1607,12 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
                 g->recv_off[c] = h.blk_off[c];
                 g->recv_cnt[c] = (uint32_t)h.need[c].size() + geo.nd_cap;
             }
+            // the rows of this share that its own rows cite: copied by pack into their block, in the sweeps' order
+            for (uint32_t l : h.need[geo.seg]) if (l >= geo.rows_cap) { set_error("internal: cited row outside the share's rows"); return ET_E_OUT_OF_RANGE; }
+            g->self_off = h.blk_off[geo.seg];
+            g->self_cnt = (uint32_t)h.need[geo.seg].size();
+            if ((size_t)g->self_off + g->self_cnt > vec_len) { set_error("internal: block of own cited entries outside the vector"); return ET_E_OUT_OF_RANGE; }
+            if ((rc = dev_upload(&g->d_self_idx, h.need[geo.seg], tot))) return rc;
             // what the other shares cite here: known now, or told later (set_send_lists) by whoever lays out all shares
             if (h.send_known) {
                 const std::vector<uint32_t>* lists[8];
@@ -1813,17 +1828,24 @@ int DeviceGraph::set_send_lists(const std::vector<uint32_t>* const lists[8]) {
     return ET_OK;
 }
 
-int DeviceGraph::pack(const void* y, void* send, size_t elem, hipStream_t st) {
-    if (!y || !send || (elem != 8 && elem != 32)) return ET_E_INVALID_ARG;
+int DeviceGraph::pack(void* y, void* send, size_t elem, hipStream_t st) {
+    if (!y || (!send && send_total) || (elem != 8 && elem != 32)) return ET_E_INVALID_ARG;
     if (geo.compact && !send_known) { set_error("this share was not told which of its rows the other shares cite"); return ET_E_UNSUPPORTED; }
     if (!geo.compact) {       // position order: a share's segment is what it sends
         if (send_total) HIP_TRY(hipMemcpyAsync(send, static_cast<const char*>(y) + (size_t)geo.own_off * elem, send_total * elem, hipMemcpyDeviceToDevice, st));
         return ET_OK;
     }
     const uint32_t n = (uint32_t)send_total;
-    if (n == 0) return ET_OK;
-    if (elem == 8) hipLaunchKernelGGL(k_pack_f64, dim3((n + 255) / 256), dim3(256), 0, st, static_cast<const double*>(y) + geo.own_off, d_send_idx, static_cast<double*>(send), n);
-    else hipLaunchKernelGGL(k_pack_fr, dim3((2 * n + 255) / 256), dim3(256), 0, st, static_cast<const uint4*>(y) + 2 * (size_t)geo.own_off, d_send_idx, static_cast<uint4*>(send), n);
+    if (n + self_cnt == 0) return ET_OK;
+    if (elem == 8) {
+        double* v = static_cast<double*>(y);
+        hipLaunchKernelGGL(k_pack_f64, dim3((n + self_cnt + 255) / 256), dim3(256), 0, st, v + geo.own_off, d_send_idx, static_cast<double*>(send), n,
+                           d_self_idx, v + self_off, self_cnt);
+    } else {
+        uint4* v = static_cast<uint4*>(y);
+        hipLaunchKernelGGL(k_pack_fr, dim3((2 * (n + self_cnt) + 255) / 256), dim3(256), 0, st, v + 2 * (size_t)geo.own_off, d_send_idx, static_cast<uint4*>(send), n,
+                           d_self_idx, v + 2 * (size_t)self_off, self_cnt);
+    }
     HIP_TRY(hipGetLastError());
     return ET_OK;
 }

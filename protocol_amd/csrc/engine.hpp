@@ -111,6 +111,9 @@ struct DeviceGraph {
     // and receives recv_cnt[p] entries from share p at recv_off[p] of the vector.  Position order: every share sends its whole
     // segment (send_off 0) and receives segment p at p * seg_stride.
     uint32_t* d_send_idx = nullptr;
+    // ... and copies the self_cnt entries its own rows cite (picked by d_self_idx) to self_off of the same vector
+    uint32_t* d_self_idx = nullptr;
+    uint32_t self_off = 0, self_cnt = 0;
     uint32_t send_off[8] = {}, send_cnt[8] = {}, recv_off[8] = {}, recv_cnt[8] = {};
     uint64_t send_total = 0;
     bool send_known = false;          // gather vector: the rows the other shares cite have been set
@@ -143,8 +146,9 @@ struct DeviceGraph {
     int stats_fr(uint32_t iteration, hipStream_t st, et_iter_stats* out);
     int run_f64(uint32_t iters, double initial, double alpha, hipStream_t st, bool record);
     int run_fr(uint32_t iters, uint64_t lo, uint64_t hi, hipStream_t st, bool record);
-    // copies the entries the other shares cite out of the own block of y into `send` (elem = 8 or 32 bytes per entry)
-    int pack(const void* y, void* send, size_t elem, hipStream_t st);
+    // copies the entries the other shares cite out of the own block of y into `send` (elem = 8 or 32 bytes per entry), and
+    // the entries the share's own rows cite into their block of y
+    int pack(void* y, void* send, size_t elem, hipStream_t st);
     // gather vector: lists[c] = the local rows of this share that share c cites, in c's order (replaces earlier lists)
     int set_send_lists(const std::vector<uint32_t>* const lists[8]);
     int record_begin(hipStream_t st);

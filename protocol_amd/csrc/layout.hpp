@@ -106,13 +106,17 @@ struct Geometry {
     uint32_t n_chunks, chunk_rows;
     // Where this share's own segment and every share's partial sums sit in the vectors the steps read and write.
     // Position order (compact == 0): own_off = seg * seg_stride(), dtail[p] = p * seg_stride() + rows_cap,
-    // vec_len = n_seg * seg_stride().  Gather vector (compact == 1): own_off = 0, block p != seg holds the cited
-    // entries of share p followed by its partial sums at dtail[p]; vec_len = entries of the gather vector.
+    // vec_len = n_seg * seg_stride().  Gather vector (compact == 1): the share's own block first (own_off = 0: its rows'
+    // entries in row order, then its partial sums at dtail[seg]), then one block per share p -- the share's own first, the
+    // others in ascending order: the cited entries of p's rows in the order this share's sweeps want them, followed (p != seg)
+    // by p's partial sums at dtail[p].  The sweeps gather from these blocks only; the own block is what a step writes,
+    // what its rows' old entries are read from, and what is packed for the others and for the share's own block of
+    // cited entries.  vec_len = entries of the gather vector.
     uint32_t compact, own_off, vec_len;
     uint32_t dtail[8];
     ET_HD uint32_t seg_stride() const { return rows_cap + nd_cap; }
-    // this share's view of the layout; with a gather vector the other shares' blocks follow once the cited rows are known
-    // (set_gather_blocks)
+    // this share's view of the layout; with a gather vector the blocks of cited entries follow once the cited rows are
+    // known (set_gather_blocks)
     ET_HD void set_share(uint32_t s) {
         seg = s;
         for (uint32_t p = 0; p < 8; ++p) dtail[p] = 0u;
@@ -126,13 +130,15 @@ struct Geometry {
         vec_len = n_seg * seg_stride();
         for (uint32_t p = 0; p < n_seg; ++p) dtail[p] = p * seg_stride() + rows_cap;
     }
-    // gather vector: block p (p != seg, ascending) = cited[p] entries of share p's rows, then its nd_cap partial sums;
-    // blk_off[p] receives the block's first entry
+    // gather vector: block p = cited[p] entries of share p's rows, then (p != seg) its nd_cap partial sums; the share's
+    // own block of cited entries comes first (what is received from the others is then one contiguous range, in share
+    // order); blk_off[p] receives the block's first entry
     ET_HD void set_gather_blocks(const uint32_t* cited, uint32_t* blk_off) {
-        uint32_t at = seg_stride();
         own_off = 0;
         for (uint32_t p = 0; p < 8; ++p) { dtail[p] = 0u; blk_off[p] = 0u; }
         dtail[seg] = rows_cap;
+        blk_off[seg] = seg_stride();
+        uint32_t at = seg_stride() + cited[seg];
         for (uint32_t p = 0; p < n_seg; ++p) {
             if (p == seg) continue;
             blk_off[p] = at;

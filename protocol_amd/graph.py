@@ -415,6 +415,8 @@ class Plan:
             grab = lambda ptr, k: (np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), (k,)).copy()
                                    if ptr and k else np.zeros(0, dtype=np.uint32))
             self.need = [grab(need[c], int(ex.recv_count[c]) - nd) if ex.gather and ex.recv_count[c] else np.zeros(0, np.uint32) for c in range(8)]
+            if ex.gather:     # the share's own cited rows: a block of the gather vector that nothing travels for
+                self.need[int(ex.seg)] = grab(need[int(ex.seg)], int(ex.self_count))
             self.send = [grab(send[c], int(ex.send_count[c]) - nd) if ex.gather and ex.send_count[c] else np.zeros(0, np.uint32) for c in range(8)]
             slots = int(info.padded_local)
             vec_len = int(info.full_len)

@@ -133,8 +133,11 @@ class ShardedGraph:
         # entries sent to / received from every other rank per exchange (nothing to itself)
         self.send_counts = [int(ex.send_count[c]) if c != self.rank else 0 for c in range(self.world)]
         self.recv_counts = [int(ex.recv_count[c]) if c != self.rank else 0 for c in range(self.world)]
+        # gather vector: own block, then the block of this rank's own cited entries (filled by the pack), then what arrives
+        self.self_count = int(ex.self_count)
         if self.gather:
-            assert self.own_off == 0 and self.vec_len == self.seg_stride + sum(self.recv_counts)
+            assert self.own_off == 0 and int(ex.self_off) == self.seg_stride
+            assert self.vec_len == self.seg_stride + self.self_count + sum(self.recv_counts)
         else:
             assert self.vec_len == self.seg_stride * self.world
         self.nnz = int(info.nnz)
@@ -185,7 +188,7 @@ class ShardedGraph:
         send = self._vec[key][:self.send_total]
         st = torch.cuda.current_stream(self.device).cuda_stream
         (self.graph.pack_f64 if kind == "f64" else self.graph.pack_fr)(t.data_ptr(), send.data_ptr(), st)
-        others = t[self.seg_stride:]                      # the other ranks' blocks, in rank order
+        others = t[self.seg_stride + self.self_count:]    # the other ranks' blocks, in rank order
         if dist.get_backend(self.group) == "nccl":
             dist.all_to_all_single(others, send, self.recv_counts, self.send_counts, group=self.group)
         else:  # gloo (CPU rendezvous, used by tests): stage through host memory

@@ -74,6 +74,16 @@ class SegmentEmulator:
         rows = [int(r) for r in self.p.send[share]] + list(range(self.rows_cap, self.stride))
         return [y[self.base + r] for r in rows]
 
+    def pack_self(self, y):
+        """The entries of this share's own rows that its own rows cite, copied into their block of y (gather vectors)."""
+        ex = self.p.exchange
+        if not self.gather:
+            return
+        rows = [int(r) for r in self.p.need[self.seg]]
+        assert len(rows) == int(ex.self_count)
+        for j, r in enumerate(rows):
+            y[int(ex.self_off) + j] = y[self.base + r]
+
     def recv_slice(self, share):
         ex = self.p.exchange
         return slice(int(ex.recv_off[share]), int(ex.recv_off[share]) + int(ex.recv_count[share]))

@@ -40,7 +40,7 @@ def assert_same_share(got, ref, rank):
     for f in ("n", "n_valid", "n_dangling", "nnz", "nnz_local", "padded_local", "n_slices", "n_work", "rows_cap", "nd_cap", "vec_len",
               "full_len", "gather"):
         assert getattr(got.info, f) == getattr(ref.info, f), f
-    for f in ("gather", "own_off", "own_len", "vec_len", "send_total"):
+    for f in ("gather", "own_off", "own_len", "vec_len", "send_total", "self_off", "self_count"):
         assert getattr(got.exchange, f) == getattr(ref.exchange, f), f
     for f in ("recv_off", "recv_count", "send_off", "send_count"):
         assert list(getattr(got.exchange, f)) == list(getattr(ref.exchange, f)), f

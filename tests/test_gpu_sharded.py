@@ -139,8 +139,10 @@ def test_all_shares_in_one_process(world, full_vector):
     stride = int(exs[0].own_len)
     assert all(bool(ex.gather) == (not full_vector) for ex in exs)
     assert int(graphs[0].info.nnz) == nnz and sum(int(g.info.nnz_local) for g in graphs) == nnz
-    if not full_vector:   # a share's vectors are shorter than the vector of all peers
-        assert all(int(ex.vec_len) < int(ex.full_len) and int(ex.own_off) == 0 for ex in exs)
+    if not full_vector:   # own block, the share's own cited entries, the other shares' cited entries and partial sums
+        assert all(int(ex.own_off) == 0 and int(ex.self_off) == stride and int(ex.self_count) <= stride and
+                   int(ex.vec_len) == stride + int(ex.self_count) + sum(int(c) for c in ex.recv_count) for ex in exs)
+        assert all(int(ex.vec_len) <= int(ex.full_len) + int(ex.self_count) for ex in exs)
 
     def exchange(vecs, kind):
         for r, (g, ex) in enumerate(zip(graphs, exs)):

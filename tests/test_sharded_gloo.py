@@ -61,6 +61,7 @@ def _worker(rank, world, port, case, ret):
             for r, vals in enumerate(all_gather_own(x, field)):
                 x[r * em.stride:(r + 1) * em.stride] = vals
             return
+        em.pack_self(x)                                  # the pack also fills the block of the share's own cited entries
         send = [em.pack(x, c) if c != rank else [] for c in range(world)]
         t_in = as_tensor([v for part in send for v in part], field)
         in_splits = [len(part) for part in send]
@@ -161,6 +162,7 @@ def test_four_and_eight_segment_layouts_in_one_process():
 
             def exchange(vecs):
                 for r, em in enumerate(ems):
+                    em.pack_self(vecs[r])
                     for q, eq in enumerate(ems):
                         if q == r:
                             continue
