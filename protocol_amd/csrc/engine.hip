@@ -195,9 +195,14 @@ struct StepArgsF64B {
 
 // PHASED: one of several launches of an iteration (chunked exchange); otherwise the launch is the whole iteration and
 // none of the phase bookkeeping is compiled in.
-template <typename VT, bool HAS_ALPHA, bool PACKED = false, bool PHASED = false>
+// EDGE: the first or the last launch of a whole converge on one GPU (first_step / out of the arguments); the launches in
+// between compile neither.
+template <typename VT, bool HAS_ALPHA, bool PACKED = false, bool PHASED = false, bool EDGE = false>
 __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
     static_assert(!(PACKED && PHASED), "runs of a chunked list do not start on a 64-edge boundary");
+    static_assert(!(EDGE && PHASED), "a whole converge runs one launch per iteration");
+    const bool first_step = EDGE && a.first_step != 0;
+    double* const out = EDGE ? a.out : nullptr;
     constexpr bool RAW = sizeof(VT) != sizeof(double);
     static_assert(!PACKED || RAW, "packed records carry integer opinions (one byte or four)");
     extern __shared__ double acc_l[];
@@ -248,11 +253,11 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
         if (pgrp[u] != 0xFFFFFFFFu) {                      // rows beyond the members read a valid address and are dropped later
             // raw form: a peer with opinions keeps no plain score between iterations (its old one is the exchanged entry
             // divided by the factor); a peer without has factor zero and keeps its plain score in `own`
-            if (RAW && row_is_dangling(a.geo, row)) pold[u] = a.first_step ? a.initial : a.own[row];
+            if (RAW && row_is_dangling(a.geo, row)) pold[u] = first_step ? a.initial : a.own[row];
             else pold[u] = xr[my_base + row];
             if (RAW) psc[u] = a.scale[row];
             if (HAS_ALPHA) ppt[u] = a.pretrust[my_base + row];
-            if (a.out) ppeer[u] = a.peer[row];
+            if (out) ppeer[u] = a.peer[row];
         }
     }
     __syncthreads();
@@ -371,11 +376,11 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
             if (first) {
                 if (live[u]) { old[u] = pold[u]; sc[u] = psc[u]; pt[u] = ppt[u]; peer[u] = ppeer[u]; }
             } else if (live[u]) {
-                if (RAW && dang[u]) old[u] = a.first_step ? a.initial : a.own[row[u]];
+                if (RAW && dang[u]) old[u] = first_step ? a.initial : a.own[row[u]];
                 else old[u] = xr[my_base + row[u]];
                 if (RAW) sc[u] = a.scale[row[u]];
                 if (HAS_ALPHA) pt[u] = a.pretrust[my_base + row[u]];
-                if (a.out) peer[u] = a.peer[row[u]];
+                if (out) peer[u] = a.peer[row[u]];
             }
             if (RAW && live[u] && !dang[u]) old[u] = old[u] / sc[u];
         }
@@ -386,8 +391,8 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
             double v = dang[u] ? s + (D - old[u]) * a.inv_nm1 : s + dterm;
             if (HAS_ALPHA) v = (1.0 - a.alpha) * v + a.alpha * pt[u];
             if (RAW && dang[u]) a.own[row[u]] = v;
-            if (a.out) {
-                if (peer[u] != 0xFFFFFFFFu) a.out[peer[u]] = v;
+            if (out) {
+                if (peer[u] != 0xFFFFFFFFu) out[peer[u]] = v;
             } else {
                 a.y[my_base + row[u]] = RAW && !a.final_step ? v * sc[u] : v;
             }
@@ -803,9 +808,13 @@ __global__ void k_scale_320(const uint4* __restrict__ scale576, uint4* __restric
 // row carries sixteen more bits beside its nine limbs (38 bytes: the tenth limbs of two rows share a 32-bit word), the
 // add that wraps the ninth limb sending its carry there.  The row's ten limbs are multiplied by inv(sum) * 2^320 and
 // reduced in one pass of ten rounds (160 limb multiply-adds per row).
-template <bool COMPACT, bool PHASED = false, bool PACKED = false, bool WIDE = false>
+// EDGE: as for the f64 sweep.
+template <bool COMPACT, bool PHASED = false, bool PACKED = false, bool WIDE = false, bool EDGE = false>
 __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
     static_assert(!(PACKED && PHASED), "runs of a chunked list do not start on a 64-edge boundary");
+    static_assert(!(EDGE && PHASED), "a whole converge runs one launch per iteration");
+    const bool first_step = EDGE && a.first_step != 0;
+    uint4* const out = EDGE ? a.out : nullptr;
     static_assert(!WIDE || (COMPACT && !PHASED), "32-bit opinions: compact rows, one launch per iteration");
     typedef typename std::conditional<WIDE, uint32_t, uint8_t>::type VT;
     const VT* __restrict__ valp = static_cast<const VT*>(a.val);
@@ -1047,7 +1056,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             peer[u] = 0xFFFFFFFFu;
             if (act[u]) {
                 factor[u] = u256_load(a.scale288 + 2 * (size_t)row[u]);
-                if (a.out) peer[u] = a.peer[row[u]];
+                if (out) peer[u] = a.peer[row[u]];
             }
         }
 #pragma unroll
@@ -1091,8 +1100,8 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
 #pragma unroll
                 for (int i = 0; i < (WIDE ? 10 : 9); ++i) full.v[i] = t[i];
                 const U256 plain = acc_redc288(full);
-                if (!a.out) u256_store(a.y + 2 * (my_base + row[u]), plain);
-                else if (peer[u] != 0xFFFFFFFFu) u256_store(a.out + 2 * (size_t)peer[u], plain);
+                if (!out) u256_store(a.y + 2 * (my_base + row[u]), plain);
+                else if (peer[u] != 0xFFFFFFFFu) u256_store(out + 2 * (size_t)peer[u], plain);
             }
         }
     }
@@ -1105,15 +1114,15 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             if (q < a.geo.n_active_pad || q >= (uint64_t)a.geo.n_active_pad + a.geo.n_dangling) continue;
             Acc full = acc_zero();
             fold_row(lr, full.v);
-            const U256 old = a.first_step ? a.initial : u256_load(a.own + 2 * (size_t)row);
+            const U256 old = first_step ? a.initial : u256_load(a.own + 2 * (size_t)row);
             fr_add_dangling_term(full, sh_d, old, a.inv_nm1_w);
             const U256 v = acc_redc288(full);
             u256_store(a.own + 2 * (size_t)row, v);
             // a dangling peer has no out-edges: its exchanged entry is never gathered
-            if (!a.out) u256_store(a.y + 2 * (my_base + row), a.final_step ? v : u256_zero());
+            if (!out) u256_store(a.y + 2 * (my_base + row), a.final_step ? v : u256_zero());
             else {
                 const uint32_t pe = a.peer[row];
-                if (pe != 0xFFFFFFFFu) u256_store(a.out + 2 * (size_t)pe, v);
+                if (pe != 0xFFFFFFFFu) u256_store(out + 2 * (size_t)pe, v);
             }
             if (a.count_changes) changed += u256_eq(v, old) ? 0u : 1u;
             dacc = fr_add(dacc, v);
@@ -1581,6 +1590,9 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
             const void* sweeps[] = {(const void*)k_step_fr_blocked<true, false, true, true>, (const void*)k_step_fr_blocked<true, false, false, true>,
                                     (const void*)k_step_fr_blocked<true, false, true>,
                                     (const void*)k_step_fr_blocked<true, false>, (const void*)k_step_fr_blocked<false, false>,
+                                    (const void*)k_step_fr_blocked<true, false, true, true, true>, (const void*)k_step_fr_blocked<true, false, false, true, true>,
+                                    (const void*)k_step_fr_blocked<true, false, true, false, true>,
+                                    (const void*)k_step_fr_blocked<true, false, false, false, true>, (const void*)k_step_fr_blocked<false, false, false, false, true>,
                                     (const void*)k_step_fr_blocked<true, true>, (const void*)k_step_fr_blocked<false, true>};
             for (const void* f : sweeps) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
             // the sweep multiplies unreduced row sums by inv(sum) * 2^288 (the resident factors carry 2^576)
@@ -1636,7 +1648,12 @@ int DeviceGraph::create(const HostGraph& h, int variants_, int device_, DeviceGr
                              (const void*)k_step_f64_blocked<uint8_t, false, false, true>, (const void*)k_step_f64_blocked<uint8_t, true, false, true>,
                              (const void*)k_step_f64_blocked<uint8_t, false>, (const void*)k_step_f64_blocked<uint8_t, true>,
                              (const void*)k_step_f64_blocked<uint32_t, false>, (const void*)k_step_f64_blocked<uint32_t, true>,
-                             (const void*)k_step_f64_blocked<double, false>, (const void*)k_step_f64_blocked<double, true>};
+                             (const void*)k_step_f64_blocked<double, false>, (const void*)k_step_f64_blocked<double, true>,
+                             (const void*)k_step_f64_blocked<uint8_t, false, true, false, true>, (const void*)k_step_f64_blocked<uint8_t, true, true, false, true>,
+                             (const void*)k_step_f64_blocked<uint32_t, false, true, false, true>, (const void*)k_step_f64_blocked<uint32_t, true, true, false, true>,
+                             (const void*)k_step_f64_blocked<uint8_t, false, false, false, true>, (const void*)k_step_f64_blocked<uint8_t, true, false, false, true>,
+                             (const void*)k_step_f64_blocked<uint32_t, false, false, false, true>, (const void*)k_step_f64_blocked<uint32_t, true, false, false, true>,
+                             (const void*)k_step_f64_blocked<double, false, false, false, true>, (const void*)k_step_f64_blocked<double, true, false, false, true>};
         for (const void* f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     }
     HIP_TRY(hipGetLastError());
@@ -1672,6 +1689,11 @@ int DeviceGraph::init_fr(uint64_t lo, uint64_t hi, uint4* x, hipStream_t st, boo
 }
 template <typename VT, bool PACKED = false, bool PHASED = false>
 static void launch_f64(const StepArgsF64B& a, unsigned blocks, size_t lds, hipStream_t st) {
+    if (!PHASED && (a.first_step || a.out)) {          // the first or last launch of a whole converge
+        if (a.alpha != 0.0) hipLaunchKernelGGL((k_step_f64_blocked<VT, true, PACKED, false, !PHASED>), dim3(blocks), dim3(1024), lds, st, a);
+        else hipLaunchKernelGGL((k_step_f64_blocked<VT, false, PACKED, false, !PHASED>), dim3(blocks), dim3(1024), lds, st, a);
+        return;
+    }
     if (a.alpha != 0.0) hipLaunchKernelGGL((k_step_f64_blocked<VT, true, PACKED, PHASED>), dim3(blocks), dim3(1024), lds, st, a);
     else hipLaunchKernelGGL((k_step_f64_blocked<VT, false, PACKED, PHASED>), dim3(blocks), dim3(1024), lds, st, a);
 }
@@ -1735,6 +1757,12 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
             if (geo.n_chunks > 1) {
                 if (geo.fr_compact) hipLaunchKernelGGL((k_step_fr_blocked<true, true>), grid, wg, lds, st, fb);
                 else hipLaunchKernelGGL((k_step_fr_blocked<false, true>), grid, wg, lds, st, fb);
+            } else if (fb.first_step || fb.out) {          // the first or last launch of a whole converge
+                if (geo.fr_compact == 2 && fr_packed) hipLaunchKernelGGL((k_step_fr_blocked<true, false, true, true, true>), grid, wg, lds, st, fb);
+                else if (geo.fr_compact == 2) hipLaunchKernelGGL((k_step_fr_blocked<true, false, false, true, true>), grid, wg, lds, st, fb);
+                else if (fr_packed) hipLaunchKernelGGL((k_step_fr_blocked<true, false, true, false, true>), grid, wg, lds, st, fb);
+                else if (geo.fr_compact) hipLaunchKernelGGL((k_step_fr_blocked<true, false, false, false, true>), grid, wg, lds, st, fb);
+                else hipLaunchKernelGGL((k_step_fr_blocked<false, false, false, false, true>), grid, wg, lds, st, fb);
             } else {
                 if (geo.fr_compact == 2 && fr_packed) hipLaunchKernelGGL((k_step_fr_blocked<true, false, true, true>), grid, wg, lds, st, fb);
                 else if (geo.fr_compact == 2) hipLaunchKernelGGL((k_step_fr_blocked<true, false, false, true>), grid, wg, lds, st, fb);
