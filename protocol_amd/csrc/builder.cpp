@@ -410,27 +410,33 @@ static void cluster_cold_sources(PlanCommon& pc, const PeerStats& st, const Buil
     // ---- cold peers: who rates them (cold raters only: a front source's lines are gathered by every workgroup anyway) ----
     std::vector<uint32_t> cidx(n, NONE);
     for (uint32_t k = 0; k < n_cold; ++k) { cidx[cold[k]] = k; cold_edges += st.in_deg[cold[k]]; }
+    // (on all host threads: the raters of a peer are only counted per workgroup, so their order in its list is free)
+    const unsigned T = host_threads();
     std::vector<uint64_t> rin_ptr((size_t)n_cold + 1, 0);
-    for (uint32_t k = 0; k < n_cold; ++k) {
-        const uint32_t f = cold[k];
-        for (uint64_t e = pc.out_ptr[f]; e < pc.out_ptr[f + 1]; ++e) {
-            if (pc.drop[e]) continue;
-            const uint32_t t = cidx[in.to[pc.kept[e]]];
-            if (t != NONE) ++rin_ptr[t + 1];
+    run_threads(T, [&](unsigned t) {
+        for (uint32_t k = (uint32_t)((uint64_t)n_cold * t / T); k < (uint32_t)((uint64_t)n_cold * (t + 1) / T); ++k) {
+            const uint32_t f = cold[k];
+            for (uint64_t e = pc.out_ptr[f]; e < pc.out_ptr[f + 1]; ++e) {
+                if (pc.drop[e]) continue;
+                const uint32_t c = cidx[in.to[pc.kept[e]]];
+                if (c != NONE) __atomic_fetch_add(&rin_ptr[c + 1], 1, __ATOMIC_RELAXED);
+            }
         }
-    }
+    });
     for (uint32_t k = 0; k < n_cold; ++k) rin_ptr[k + 1] += rin_ptr[k];
     std::vector<uint32_t> rin(rin_ptr[n_cold]);
     {
         std::vector<uint64_t> cur(rin_ptr.begin(), rin_ptr.end() - 1);
-        for (uint32_t k = 0; k < n_cold; ++k) {
-            const uint32_t f = cold[k];
-            for (uint64_t e = pc.out_ptr[f]; e < pc.out_ptr[f + 1]; ++e) {
-                if (pc.drop[e]) continue;
-                const uint32_t t = cidx[in.to[pc.kept[e]]];
-                if (t != NONE) rin[cur[t]++] = f;
+        run_threads(T, [&](unsigned t) {
+            for (uint32_t k = (uint32_t)((uint64_t)n_cold * t / T); k < (uint32_t)((uint64_t)n_cold * (t + 1) / T); ++k) {
+                const uint32_t f = cold[k];
+                for (uint64_t e = pc.out_ptr[f]; e < pc.out_ptr[f + 1]; ++e) {
+                    if (pc.drop[e]) continue;
+                    const uint32_t c = cidx[in.to[pc.kept[e]]];
+                    if (c != NONE) rin[__atomic_fetch_add(&cur[c], 1, __ATOMIC_RELAXED)] = f;
+                }
             }
-        }
+        });
     }
     const double t_lp = now_s();
     // ---- label propagation under capacity ----
@@ -454,7 +460,6 @@ static void cluster_cold_sources(PlanCommon& pc, const PeerStats& st, const Buil
     // from the labels as they stand (the earlier slices of this round included), the three best labels per peer are kept,
     // and the peers are then placed one after the other under the capacities: the outcome does not depend on the thread count.
     const uint32_t SLICES = 8, KEEP = 3;
-    const unsigned T = host_threads();
     std::vector<uint32_t> cand((size_t)n_cold * KEEP, NONE);
     auto mix = [](uint32_t f, uint32_t l) { uint64_t z = ((uint64_t)f << 20 ^ l) * 0x9E3779B97F4A7C15ull; return z ^ (z >> 29); };
     for (uint32_t round = 0; round < rounds; ++round) {
@@ -548,7 +553,7 @@ static void cluster_cold_sources(PlanCommon& pc, const PeerStats& st, const Buil
     });
     std::vector<uint32_t> by_key(n_cold);
     std::iota(by_key.begin(), by_key.end(), 0u);
-    std::sort(by_key.begin(), by_key.end(), [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] < key[b] : cold[a] < cold[b]; });
+    parallel_sort(by_key.begin(), by_key.end(), [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] < key[b] : cold[a] < cold[b]; }, T);
     for (uint32_t r = 0; r < n_front; ++r) order[r] = front[r];
     {
         // a workgroup's peers fill whole groups; the few beyond its last whole group join the peers without a workgroup, which
@@ -1061,7 +1066,16 @@ int deal_segment(HostGraph& g, const BuildOpts& opt, Src& src, DealtSegment& ds)
         g.grp_hint.assign(dfr.block.begin(), dfr.block.begin() + first_dangling_group);
         g.hint_blocks = geo.fr_blocks;
     }
-    ds.d64 = deal(geo.f64_blocks, geo.f64_rb / BLOCK_GROUP, geo.f64_dblocks, g.bk_grp, g.bk_ptr);
+    // Equally many workgroups in both sweeps and room for the exact sweep's rows in the f64 sweep's workgroups: one deal
+    // serves both (it is levelled by the same edge counts), and the edge lists are then written once (fill_segment)
+    const uint32_t gpb64 = geo.f64_rb / BLOCK_GROUP;
+    if (geo.fr_blocks == geo.f64_blocks && geo.f64_rb >= geo.fr_rb && geo.f64_dblocks >= geo.fr_dblocks && !getenv("ET_SEPARATE_DEALS")) {
+        ds.d64 = dfr;
+        g.bk_ptr = g.fb_ptr;
+        g.bk_grp.assign((size_t)geo.f64_blocks * gpb64, 0xFFFFFFFFu);
+        for (uint32_t gi = 0; gi < n_groups; ++gi) g.bk_grp[(size_t)dfr.block[gi] * gpb64 + dfr.slot[gi]] = gi;
+    } else
+    ds.d64 = deal(geo.f64_blocks, gpb64, geo.f64_dblocks, g.bk_grp, g.bk_ptr);
     if (cluster) {
         // sources cited this often by the share's rows stay in front, in position order: nearly every workgroup gathers them
         const uint32_t hot = getenv("ET_CLUSTER_HOT") ? (uint32_t)atoi(getenv("ET_CLUSTER_HOT")) : 16u;   // 8 / 16 / 32 measured: 140.5 / 131.3 / 134.6 us (f64 share of eight)
@@ -1152,6 +1166,21 @@ int fill_segment(HostGraph& g, const BuildOpts& opt, const Src& src, unsigned T,
             std::vector<uint32_t> owner_fr(BF, 0);
             for (unsigned t = 0; t < T; ++t)
                 for (uint32_t bb = (uint32_t)((uint64_t)BF * t / T); bb < (uint32_t)((uint64_t)BF * (t + 1) / T); ++bb) owner_fr[bb] = t;
+            // Both sweeps gave every row group to the same workgroup (the usual case when they run equally many): the exact
+            // sweep's lists are the f64 sweep's with the rows' accumulator slots renamed, no second pass over the edges
+            if (g.values_are_u32 && BF == B64 && dfr.block == d64.block && g.fb_ptr == g.bk_ptr) {
+                const uint32_t gpb64 = geo.f64_rb / BLOCK_GROUP;
+                run_threads(T, [&](unsigned t) {
+                    for (uint32_t bb = (uint32_t)((uint64_t)BF * t / T); bb < (uint32_t)((uint64_t)BF * (t + 1) / T); ++bb)
+                        for (uint64_t q = g.bk_ptr[bb]; q < g.bk_ptr[bb + 1]; ++q) {
+                            const uint32_t slot64 = g.bk_row[q], grp = g.bk_grp[(size_t)bb * gpb64 + slot64 / BLOCK_GROUP];
+                            g.fb_col[q] = g.bk_col[q];
+                            g.fb_row[q] = (uint16_t)(dfr.slot[grp] * BLOCK_GROUP + slot64 % BLOCK_GROUP);
+                            if (wide) g.fb_val_u32[q] = g.bk_val_u32[q];
+                            else g.fb_val[q] = (uint8_t)g.bk_val_u32[q];
+                        }
+                });
+            } else
             scatter([&](uint32_t lr) { return (unsigned)owner_fr[dfr.block[lr / BLOCK_GROUP]]; },
                     [&](const Entry& e) {
                         const uint32_t grp = e.lr / BLOCK_GROUP;
