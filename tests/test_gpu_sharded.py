@@ -112,16 +112,17 @@ def test_two_ranks_with_cited_entries_ordered_by_workgroup():
     assert float(np.abs(got - eld).sum() / np.abs(eld).sum()) <= 1e-9
 
 
-@pytest.mark.parametrize("world,full_vector", [(4, False), (8, False), (4, True)])
-def test_all_shares_in_one_process(world, full_vector):
+@pytest.mark.parametrize("world,full_vector,value_max", [(4, False, 255), (8, False, 255), (4, True, 255), (4, False, 2**32 - 1)])
+def test_all_shares_in_one_process(world, full_vector, value_max):
     """The kernels on the layouts of 4 and 8 shares (what the 4- and 8-GPU runs execute), every share held by
     this one process and the exchange done as device copies: the cited entries packed by the producer into the
-    consumers' gather vectors, or whole segments in position order (full_vector)."""
+    consumers' gather vectors, or whole segments in position order (full_vector).  Byte opinions and 32-bit ones (the
+    exact sweep's ten-limb rows on gather vectors)."""
     import torch
     import c_oracle
     import protocol_amd as pa
     n = 60000
-    frm, to, val = pa.synth_graph(3, n, 16 * n, seed=9, value_max=255)
+    frm, to, val = pa.synth_graph(3, n, 16 * n, seed=9, value_max=value_max)
     member = np.ones(n, dtype=np.uint8)
     member[::89] = 0
     iters = 20
