@@ -44,7 +44,7 @@ pub const ET_VARIANT_FR: u32 = 1;
 pub const ET_VARIANT_F64: u32 = 2;
 pub const ET_INIT_PLAIN: u32 = 1;
 pub const ET_STEP_FINAL: u32 = 1;
-pub const ET_STEP_NO_CHANGED: u32 = 2;
+pub const ET_STEP_NO_STATS: u32 = 2;
 
 #[repr(C)]
 pub struct et_set {

@@ -260,9 +260,11 @@ int et_graph_init_f64_async(et_graph *g, double initial, void *x, uint32_t flags
  * output holds plain scores and is the only one et_graph_unpermute_* may be given.  A vector
  * written by et_graph_init_* must go through at least one step before it is read back. */
 #define ET_STEP_FINAL 1u
-/* The exact step does not read the old entries to count the rows that changed (32 bytes per row less to move):
- * et_iter_stats.changed of that iteration reads 0.  A converge sets it on every step but the last. */
-#define ET_STEP_NO_CHANGED 2u
+/* No statistics for this iteration: the exact step does not read the old entries to count the rows that changed (32
+ * bytes per row less to move) and forms no score sum, the f64 step reads no old entry and forms neither residual nor
+ * score sum (a division per row less).  et_iter_stats of that iteration is not meaningful (zeros, except where a
+ * workgroup holding dangling rows added up its own).  A converge sets it on every step but the last. */
+#define ET_STEP_NO_STATS 2u
 int et_graph_step_fr_async(et_graph *g, const void *x, void *y, uint32_t iteration, uint32_t flags,
                            void *stream);
 int et_graph_step_f64_async(et_graph *g, const void *x, void *y, uint32_t iteration, double alpha,

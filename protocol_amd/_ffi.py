@@ -116,7 +116,7 @@ class EtIterStats(C.Structure):
 vp, u32, u64, i32, dbl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
 P = C.POINTER
 ET_STEP_FINAL = 1
-ET_STEP_NO_CHANGED = 2
+ET_STEP_NO_STATS = 2
 ET_INIT_PLAIN = 1
 
 PROTOTYPES = {

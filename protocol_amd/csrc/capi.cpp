@@ -313,7 +313,7 @@ int et_graph_converge_f64(et_graph* g, uint32_t num_iterations, double initial, 
         if ((rc = d->init_f64(initial, d->vx[0], nullptr, num_iterations == 0))) return rc;
         for (uint32_t it = 0; it < num_iterations; ++it)
             if ((rc = d->step_f64(d->vx[it & 1], d->vx[(it + 1) & 1], it, alpha, d->d_pretrust,
-                                  it + 1 == num_iterations ? ET_STEP_FINAL : 0u, nullptr))) return rc;
+                                  it + 1 == num_iterations ? ET_STEP_FINAL : ET_STEP_NO_STATS, nullptr))) return rc;
         if ((rc = d->unpermute_f64(d->vx[num_iterations & 1], d->out_f64, nullptr))) return rc;
     } else {
         if ((rc = d->run_f64(num_iterations, initial, alpha, nullptr, false))) return rc;

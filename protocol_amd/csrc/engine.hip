@@ -191,6 +191,9 @@ struct StepArgsF64B {
     double initial;
     double* out;
     const uint32_t* peer;     // [rows_cap] slot of the peer at a position, ~0 = none
+    // residual and score sum of this iteration wanted (a converge asks on its last step only): without them a row with
+    // opinions needs neither its old entry nor the division that turns it back into a score
+    uint32_t stats;
 };
 
 // PHASED: one of several launches of an iteration (chunked exchange); otherwise the launch is the whole iteration and
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
             // raw form: a peer with opinions keeps no plain score between iterations (its old one is the exchanged entry
             // divided by the factor); a peer without has factor zero and keeps its plain score in `own`
             if (RAW && row_is_dangling(a.geo, row)) pold[u] = first_step ? a.initial : a.own[row];
-            else pold[u] = xr[my_base + row];
+            else if (!RAW || a.stats) pold[u] = xr[my_base + row];
             if (RAW) psc[u] = a.scale[row];
             if (HAS_ALPHA) ppt[u] = a.pretrust[my_base + row];
             if (out) ppeer[u] = a.peer[row];
@@ -377,12 +380,12 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
                 if (live[u]) { old[u] = pold[u]; sc[u] = psc[u]; pt[u] = ppt[u]; peer[u] = ppeer[u]; }
             } else if (live[u]) {
                 if (RAW && dang[u]) old[u] = first_step ? a.initial : a.own[row[u]];
-                else old[u] = xr[my_base + row[u]];
+                else if (!RAW || a.stats) old[u] = xr[my_base + row[u]];
                 if (RAW) sc[u] = a.scale[row[u]];
                 if (HAS_ALPHA) pt[u] = a.pretrust[my_base + row[u]];
                 if (out) peer[u] = a.peer[row[u]];
             }
-            if (RAW && live[u] && !dang[u]) old[u] = old[u] / sc[u];
+            if (RAW && a.stats && live[u] && !dang[u]) old[u] = old[u] / sc[u];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -396,13 +399,16 @@ __global__ __launch_bounds__(1024) void k_step_f64_blocked(StepArgsF64B a) {
             } else {
                 a.y[my_base + row[u]] = RAW && !a.final_step ? v * sc[u] : v;
             }
-            res += fabs(v - old[u]);
-            tot += v;
+            if (a.stats) { res += fabs(v - old[u]); tot += v; }
             if (dang[u]) dacc += v;
         }
     }
-    res = wave_sum_f64(res);
-    tot = wave_sum_f64(tot);
+    // without statistics only the workgroups that hold dangling rows have anything to add up
+    if (!a.stats && b >= a.geo.f64_dblocks) {
+        if (threadIdx.x == 0) { a.res_part[b] = 0.0; a.sum_part[b] = 0.0; }
+        return;
+    }
+    if (a.stats) { res = wave_sum_f64(res); tot = wave_sum_f64(tot); }
     dacc = wave_sum_f64(dacc);
     if (lane == 0) { red[0][wave] = res; red[1][wave] = tot; red[2][wave] = dacc; }
     __syncthreads();
@@ -765,7 +771,8 @@ struct StepArgsFrB {
     U256 inv_nm1_w576;        // inv(n_valid - 1) * 2^576
     uint32_t bar_period;      // passes between two barriers of the sweep
     uint32_t bar_first_256;   // the first one after this many 256ths of the workgroup's passes
-    // count the rows whose entry changed (one more 32-byte load per row); a converge asks for it on its last step only
+    // statistics of this iteration wanted: the rows whose entry changed (one more 32-byte load per row) and the score sum
+    // (ten-limb additions per row and the reductions at the end); a converge asks for them on its last step only
     uint32_t count_changes;
     // a whole converge on one GPU (run_fr), as for the f64 sweep: dangling rows' old score on the first step, and the
     // last step's scores written in slot order
@@ -1076,7 +1083,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
                 if (WIDE) { c += t[8]; t[8] = (uint32_t)c; t[9] += (uint32_t)(c >> 32); }
                 else t[8] += (uint32_t)c;
             }
-            {
+            if (a.count_changes) {       // statistics wanted: the integer sum of the T is the score sum before reduction
                 uint64_t c = 0;
 #pragma unroll
                 for (int i = 0; i < (WIDE ? 10 : 9); ++i) {
@@ -1127,6 +1134,11 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
             if (a.count_changes) changed += u256_eq(v, old) ? 0u : 1u;
             dacc = fr_add(dacc, v);
         }
+    }
+    // without statistics only the workgroups that hold dangling rows have anything to add up
+    if (!a.count_changes && b >= a.geo.fr_dblocks) {
+        if (threadIdx.x == 0) { u256_store(a.sum_part + 2 * (size_t)b, u256_zero()); a.chg_part[b] = 0u; }
+        return;
     }
     // per wavefront: integer sum of the T, field sum of the dangling rows' scores (leading workgroups only), count
     acc10_group_sum(traw, 64);
@@ -1711,6 +1723,7 @@ int DeviceGraph::step_f64(const double* x, double* y, uint32_t iteration, double
     a.geo = geo; a.inv_nm1 = inv_nm1; a.alpha = alpha; a.final_step = (flags & ET_STEP_FINAL) ? 1u : 0u;
     a.phase_ptr = d_bk_phase; a.acc_g = d_f64_acc; a.n_phases = geo.n_chunks;
     a.bar_period = f64_bar_period; a.bar_first_256 = f64_bar_first_256;
+    a.stats = (flags & ET_STEP_NO_STATS) ? 0u : 1u;
     a.first_step = ex && ex->first_step ? 1u : 0u; a.initial = ex ? ex->initial64 : 0.0;
     a.out = ex && a.final_step ? static_cast<double*>(ex->out) : nullptr; a.peer = d_peer;
     if (a.out && (!d_peer || geo.n_chunks != 1)) { set_error("internal: scores in slot order need the whole graph in one launch"); return ET_E_UNSUPPORTED; }
@@ -1745,7 +1758,7 @@ int DeviceGraph::step_fr(const uint4* x, uint4* y, uint32_t iteration, uint32_t 
         fb.inv_nm1_w576 = to_u256((Fr::from_raw(inv_nm1_w) * Fr::one().pow2k(288)).to_raw());
         fb.phase_ptr = d_fb_phase; fb.acc_g = d_fr_acc; fb.n_phases = geo.n_chunks;
         fb.bar_period = fr_bar_period; fb.bar_first_256 = fr_bar_first_256;
-        fb.count_changes = (flags & ET_STEP_NO_CHANGED) ? 0u : 1u;
+        fb.count_changes = (flags & ET_STEP_NO_STATS) ? 0u : 1u;
         fb.first_step = ex && ex->first_step ? 1u : 0u; fb.initial = to_u256(ex ? ex->initial_fr : FrRaw{});
         fb.out = ex && fb.final_step ? static_cast<uint4*>(ex->out) : nullptr; fb.peer = d_peer;
         if (fb.out && (!d_peer || geo.n_chunks != 1)) { set_error("internal: scores in slot order need the whole graph in one launch"); return ET_E_UNSUPPORTED; }
@@ -1947,7 +1960,7 @@ int DeviceGraph::run_f64(uint32_t iters, double initial, double alpha, hipStream
     ex.out = out_f64;
     if (record && (rc = record_begin(st))) return rc;
     for (uint32_t it = 0; it < iters; ++it) {
-        const uint32_t flags = it + 1 == iters ? ET_STEP_FINAL : 0u;
+        const uint32_t flags = it + 1 == iters ? ET_STEP_FINAL : ET_STEP_NO_STATS;      // a converge reports its last step's figures
         if (!fused) rc = step_f64(vx[it & 1], vx[(it + 1) & 1], it, alpha, pre, flags, st);
         else {
             ex.first_step = it == 0;
@@ -1986,7 +1999,7 @@ int DeviceGraph::run_fr(uint32_t iters, uint64_t lo, uint64_t hi, hipStream_t st
     if (record && (rc = record_begin(st))) return rc;
     for (uint32_t it = 0; it < iters; ++it) {
         // the number of changed rows is asked of the last step only (what a converge reports)
-        const uint32_t flags = it + 1 == iters ? ET_STEP_FINAL : ET_STEP_NO_CHANGED;
+        const uint32_t flags = it + 1 == iters ? ET_STEP_FINAL : ET_STEP_NO_STATS;
         if (!fused) rc = step_fr(fx[it & 1], fx[(it + 1) & 1], it, flags, st);
         else {
             ex.first_step = it == 0;

@@ -449,7 +449,7 @@ int et_sharded_converge_fr(et_sharded* s, uint32_t num_iterations, uint64_t init
     else if (num_iterations && (rc = s->exchange_segments(0, 32))) return rc;
     for (uint32_t it = 0; it < num_iterations; ++it) {
         const int a = it & 1, b = (it + 1) & 1;
-        const uint32_t flags = it + 1 == num_iterations ? ET_STEP_FINAL : ET_STEP_NO_CHANGED;
+        const uint32_t flags = it + 1 == num_iterations ? ET_STEP_FINAL : ET_STEP_NO_STATS;
         for (uint32_t q = 0; q < s->n_chunks; ++q)
             for (uint32_t r = 0; r < s->world; ++r) {
                 HIP_TRY_S(hipSetDevice(s->device[r]));
@@ -515,7 +515,7 @@ int et_sharded_converge_f64(et_sharded* s, uint32_t num_iterations, double initi
     else if (num_iterations && (rc = s->exchange_segments(0, 8))) return rc;
     for (uint32_t it = 0; it < num_iterations; ++it) {
         const int a = it & 1, b = (it + 1) & 1;
-        const uint32_t flags = it + 1 == num_iterations ? ET_STEP_FINAL : 0u;
+        const uint32_t flags = it + 1 == num_iterations ? ET_STEP_FINAL : ET_STEP_NO_STATS;
         for (uint32_t q = 0; q < s->n_chunks; ++q)
             for (uint32_t r = 0; r < s->world; ++r) {
                 HIP_TRY_S(hipSetDevice(s->device[r]));

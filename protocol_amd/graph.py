@@ -272,21 +272,23 @@ class Graph:
     def init_f64(self, x_ptr, initial=1000.0, stream=None, plain=False):
         check(lib().et_graph_init_f64_async(self._h, initial, x_ptr, 1 if plain else 0, stream))
 
-    def step_fr(self, x_ptr, y_ptr, iteration, stream=None, final=False, phase=None, count_changes=True):
+    def step_fr(self, x_ptr, y_ptr, iteration, stream=None, final=False, phase=None, stats=True):
         """One iteration; `final=True` on the last step of a converge (its output holds plain scores).
         `phase`: one of the info.n_chunks launches of the iteration (graphs built with n_chunks > 1), None = all.
-        `count_changes=False`: the step does not read the old entries, stats_fr reports 0 changed rows for it."""
-        flags = (_ffi.ET_STEP_FINAL if final else 0) | (0 if count_changes else _ffi.ET_STEP_NO_CHANGED)
+        `stats=False`: the step does not read the old entries, stats_fr reports 0 changed rows for it."""
+        flags = (_ffi.ET_STEP_FINAL if final else 0) | (0 if stats else _ffi.ET_STEP_NO_STATS)
         if phase is None:
             check(lib().et_graph_step_fr_async(self._h, x_ptr, y_ptr, iteration, flags, stream))
         else:
             check(lib().et_graph_step_fr_phase_async(self._h, x_ptr, y_ptr, iteration, flags, phase, stream))
 
-    def step_f64(self, x_ptr, y_ptr, iteration, alpha=0.0, pretrust_ptr=None, stream=None, final=False, phase=None):
+    def step_f64(self, x_ptr, y_ptr, iteration, alpha=0.0, pretrust_ptr=None, stream=None, final=False, phase=None, stats=True):
+        """`stats=False`: neither residual nor score sum for this iteration (stats_f64 reports zeros for it)."""
+        flags = (_ffi.ET_STEP_FINAL if final else 0) | (0 if stats else _ffi.ET_STEP_NO_STATS)
         if phase is None:
-            check(lib().et_graph_step_f64_async(self._h, x_ptr, y_ptr, iteration, alpha, pretrust_ptr, 1 if final else 0, stream))
+            check(lib().et_graph_step_f64_async(self._h, x_ptr, y_ptr, iteration, alpha, pretrust_ptr, flags, stream))
         else:
-            check(lib().et_graph_step_f64_phase_async(self._h, x_ptr, y_ptr, iteration, alpha, pretrust_ptr, 1 if final else 0, phase, stream))
+            check(lib().et_graph_step_f64_phase_async(self._h, x_ptr, y_ptr, iteration, alpha, pretrust_ptr, flags, phase, stream))
 
     def exchange(self):
         """What this share sends to and receives from the others between two steps (et_exchange_info)."""

@@ -295,9 +295,9 @@ class ShardedGraph:
                 if record:
                     g.record_begin(st)
                 if kind == "f64":
-                    g.step_f64(a.data_ptr(), b.data_ptr(), it, alpha, pre, st, final=final, phase=q)
+                    g.step_f64(a.data_ptr(), b.data_ptr(), it, alpha, pre, st, final=final, phase=q, stats=final)
                 else:
-                    g.step_fr(a.data_ptr(), b.data_ptr(), it, st, final=final, phase=q, count_changes=final)
+                    g.step_fr(a.data_ptr(), b.data_ptr(), it, st, final=final, phase=q, stats=final)
                 if record:
                     g.record_end(st)
             pend = self._start_exchange(b, kind)
@@ -334,7 +334,7 @@ class ShardedGraph:
             a, b = bufs[it & 1], bufs[(it + 1) & 1]
             if record:
                 g.record_begin(st)
-            g.step_f64(a.data_ptr(), b.data_ptr(), it, alpha, pre, st, final=it + 1 == num_iterations)
+            g.step_f64(a.data_ptr(), b.data_ptr(), it, alpha, pre, st, final=it + 1 == num_iterations, stats=it + 1 == num_iterations)
             if record:
                 g.record_end(st)
             if it + 1 < num_iterations:
@@ -358,7 +358,7 @@ class ShardedGraph:
             a, b = bufs[it & 1], bufs[(it + 1) & 1]
             if record:
                 g.record_begin(st)
-            g.step_fr(a.data_ptr(), b.data_ptr(), it, st, final=it + 1 == num_iterations, count_changes=it + 1 == num_iterations)
+            g.step_fr(a.data_ptr(), b.data_ptr(), it, st, final=it + 1 == num_iterations, stats=it + 1 == num_iterations)
             if record:
                 g.record_end(st)
             if it + 1 < num_iterations:

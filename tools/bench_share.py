@@ -62,9 +62,9 @@ def main():
             def launch(it):
                 a, b = bufs[it & 1], bufs[(it + 1) & 1]
                 if kind_ == "f64":
-                    step(a.data_ptr(), b.data_ptr(), it, 0.0, None, st)
+                    step(a.data_ptr(), b.data_ptr(), it, 0.0, None, st, stats=False)
                 else:
-                    step(a.data_ptr(), b.data_ptr(), it, st, count_changes=False)      # as every step of a converge but the last
+                    step(a.data_ptr(), b.data_ptr(), it, st, stats=False)      # as every step of a converge but the last
             for it in range(3):
                 launch(it)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
