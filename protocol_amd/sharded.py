@@ -76,7 +76,8 @@ def distributed_plan(n, frm, to, value_u32, member=None, group=None, world=1, ra
     del got
     if plan.info().gather:
         # gather vectors: every rank tells the others which of their rows it cites (they pack those after every step)
-        needs = [plan.needs(s) for s in range(world)]
+        # (what it cites of its OWN rows stays here: the block of the share's own cited entries is filled by its own pack)
+        needs = [plan.needs(s) if s != rank else np.zeros(0, dtype=np.uint32) for s in range(world)]
         send = [len(x) for x in needs]
         counts = torch.tensor(send, dtype=torch.int64, device=comm_device)
         all_counts = [torch.empty_like(counts) for _ in range(world)]
