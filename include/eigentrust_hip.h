@@ -262,8 +262,8 @@ int et_graph_init_f64_async(et_graph *g, double initial, void *x, uint32_t flags
 #define ET_STEP_FINAL 1u
 /* No statistics for this iteration: the exact step does not read the old entries to count the rows that changed (32
  * bytes per row less to move) and forms no score sum, the f64 step reads no old entry and forms neither residual nor
- * score sum (a division per row less).  et_iter_stats of that iteration is not meaningful (zeros, except where a
- * workgroup holding dangling rows added up its own).  A converge sets it on every step but the last. */
+ * score sum (a division per row less).  et_iter_stats of that iteration is unspecified (zeros from the blocked sweeps;
+ * the row-per-lane kernels form their statistics regardless).  A converge sets it on every step but the last. */
 #define ET_STEP_NO_STATS 2u
 int et_graph_step_fr_async(et_graph *g, const void *x, void *y, uint32_t iteration, uint32_t flags,
                            void *stream);

@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(1024) void k_step_fr_blocked(StepArgsFrB a) {
         if (lane == 0) {
             // score sum of the workgroup's rows: the dangling rows' plain scores plus the reduced integer sum of the T
             // (at most 4400 rows below 2^287 each, or 4240 below 2^304: ten limbs)
-            u256_store(a.sum_part + 2 * (size_t)b, fr_add(d, acc_redc288(acc_from_acc10(r10))));
+            u256_store(a.sum_part + 2 * (size_t)b, a.count_changes ? fr_add(d, acc_redc288(acc_from_acc10(r10))) : u256_zero());
             a.chg_part[b] = ch;
             if (b < a.geo.fr_dblocks) u256_store(a.y + 2 * (my_base + a.geo.rows_cap + b), d);   // partial sum slot b
         }

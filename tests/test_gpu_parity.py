@@ -224,6 +224,43 @@ def test_converges_in_a_row_with_other_initial_scores_and_iteration_counts(fused
     assert rel_l1(o64, eld) <= F64_TOL
 
 
+def test_steps_without_statistics_write_the_same_scores():
+    # ET_STEP_NO_STATS: a step that forms neither residual nor score sum nor the count of changed rows (what every step of a
+    # converge but the last asks for) writes the same vector as one that does
+    import torch
+    rng = np.random.default_rng(123)
+    n = 9000
+    member, frm, to, val = random_graph(rng, n, 12, 0.03, 0.15, 255, hub=True)
+    g = pa.Graph(n, frm, to, value_u32=val, member=member)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    vec_len = int(g.info.vec_len)
+    for kind in ("fr", "f64"):
+        outs = []
+        for stats in (True, False):
+            mk = (lambda: torch.zeros((vec_len, 4), dtype=torch.int64, device=dev)) if kind == "fr" else (lambda: torch.zeros(vec_len, dtype=torch.float64, device=dev))
+            x, y = mk(), mk()
+            (g.init_fr if kind == "fr" else g.init_f64)(x.data_ptr(), 1000, st)
+            for it in range(3):
+                if kind == "fr":
+                    g.step_fr(x.data_ptr(), y.data_ptr(), it, st, final=it == 2, stats=stats)
+                else:
+                    g.step_f64(x.data_ptr(), y.data_ptr(), it, 0.0, None, st, final=it == 2, stats=stats)
+                x, y = y, x
+            torch.cuda.synchronize(dev)
+            outs.append(x.cpu().numpy().copy())
+            if kind == "fr":
+                total, changed = g.stats_fr(1, st)
+                assert not stats or (total == 1000 * int(member.sum()) % R and changed > 0)     # without: unspecified
+            else:
+                res, total = g.stats_f64(1, st)
+                assert not stats or (res > 0.0 and abs(total - 1000.0 * member.sum()) < 1e-6 * total)
+        if kind == "fr":
+            assert np.array_equal(outs[0], outs[1])
+        else:
+            assert np.allclose(outs[0], outs[1], rtol=1e-12, atol=0.0)
+
+
 def test_no_attestations_at_all():
     # every member is dangling: each gives 1 to every other member (native.rs:263-278), scores stay put
     n = 70
